@@ -1,0 +1,170 @@
+/*
+ * vcg.h -- C ABI of the MI355X (gfx950) hot-path library  libvcg_hip.so
+ *
+ * Scope: the generator / discriminator forward+backward train step of
+ * kjedrzejewski/video-cycle_gan-upscaling.  The reference has NO FFI / plugin
+ * boundary of its own (it is pure Keras); every entry point below replaces one third-party Keras/TF
+ * primitive at the call site quoted next to it (paths relative to the reference root).
+ *
+ * Conventions
+ *   - all tensors are fp32, contiguous, NCHW on the device; kernels keep Keras' layouts:
+ *       Conv2D          kernel (kh,kw,in,out)  "HWIO"   + its per-tap transpose (kh,kw,out,in) "HWOI"
+ *       Conv2DTranspose kernel (kh,kw,out,in)  "HWOI"   + its per-tap transpose "HWIO"
+ *       Dense           kernel (in,out)
+ *   - the library never allocates, frees or synchronises: the caller passes every buffer and a
+ *     workspace (size from the *_workspace_bytes query); every call is asynchronous on `stream`
+ *     and hipGraph-capturable;
+ *   - return value: 0 ok; <0 invalid argument (VCG_E_*); >0 a hipError_t;
+ *   - entry points are re-entrant and stateless.
+ */
+#ifndef VCG_H
+#define VCG_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* vcg_stream_t; /* a hipStream_t */
+
+enum {
+    VCG_OK = 0,
+    VCG_E_NULL = -1,        /* required pointer is NULL              */
+    VCG_E_SHAPE = -2,       /* inconsistent / unsupported dimensions */
+    VCG_E_UNSUPPORTED = -3, /* kernel size / stride not instantiated */
+    VCG_E_WORKSPACE = -4    /* workspace too small                   */
+};
+
+enum { VCG_ACT_NONE = 0, VCG_ACT_LRELU = 1, VCG_ACT_PRELU = 2, VCG_ACT_TANH = 3 };
+enum { VCG_NORM_BATCH = 0, VCG_NORM_INSTANCE = 1 };
+enum { VCG_LOSS_MSE = 0, VCG_LOSS_MAE = 1 };
+
+/* A Keras Conv2D / Conv2DTranspose call site.  For Conv2D  (n,cin,h,w) -> (n,cout,oh,ow);
+ * pad_top/pad_left are the TF-SAME "before" pads (bottom/right follow from oh/ow).
+ * For Conv2DTranspose (n,cin,h,w) -> (n,cout,oh,ow) with oh<=h*stride; pad_top/pad_left are the
+ * crop-before amounts floor((k-s)/2) of the full transposed convolution. */
+typedef struct vcg_conv_desc {
+    int32_t n, cin, h, w;
+    int32_t cout, oh, ow;
+    int32_t kh, kw, stride;
+    int32_t pad_top, pad_left;
+} vcg_conv_desc;
+
+/* Fused output stage: y = act(acc + bias) + residual */
+typedef struct vcg_epilogue {
+    const float* bias;        /* [cout] or NULL                        */
+    int32_t act;              /* VCG_ACT_*                             */
+    float act_alpha;          /* LeakyReLU slope                       */
+    const float* prelu_alpha; /* [cout] per-channel slope (ACT_PRELU)  */
+    const float* residual;    /* same shape as the output, or NULL     */
+} vcg_epilogue;
+
+const char* vcg_version(void);
+const char* vcg_error_string(int code);
+
+/* ---- Conv2D: keras.layers.Conv2D at upscaling/upscaler/model.py:19,22,275,283,290 (generator),
+ *      :839-871 / :904-936 (discriminators), :65 (downsampling_block) -------------------------- */
+int vcg_conv2d_fwd(const vcg_conv_desc* d, const float* x, const float* w_hwio, float* y,
+                   const vcg_epilogue* ep, vcg_stream_t stream);
+/* dx = dL/dx given dy; `residual` (optional, shape of dx) is added: dx = dgrad + residual */
+int vcg_conv2d_dgrad(const vcg_conv_desc* d, const float* dy, const float* w_hwio, const float* w_hwoi,
+                     float* dx, const float* residual, vcg_stream_t stream);
+size_t vcg_conv2d_wgrad_workspace_bytes(const vcg_conv_desc* d);
+/* dw_hwio (overwritten), dbias (overwritten, may be NULL) */
+int vcg_conv2d_wgrad(const vcg_conv_desc* d, const float* x, const float* dy, float* dw_hwio, float* dbias,
+                     void* ws, size_t ws_bytes, vcg_stream_t stream);
+
+/* ---- Conv2DTranspose(strides=2, padding='same'): upscaling/upscaler/model.py:72 ---------------- */
+int vcg_conv_transpose2d_fwd(const vcg_conv_desc* d, const float* x, const float* w_hwio_t, float* y,
+                             const vcg_epilogue* ep, vcg_stream_t stream);
+int vcg_conv_transpose2d_dgrad(const vcg_conv_desc* d, const float* dy, const float* w_hwoi, float* dx,
+                               const float* residual, vcg_stream_t stream);
+size_t vcg_conv_transpose2d_wgrad_workspace_bytes(const vcg_conv_desc* d);
+int vcg_conv_transpose2d_wgrad(const vcg_conv_desc* d, const float* x, const float* dy, float* dw_hwoi,
+                               float* dbias, void* ws, size_t ws_bytes, vcg_stream_t stream);
+
+/* per-tap transpose of a kernel: (taps, a, b) -> (taps, b, a) */
+int vcg_kernel_transpose(const float* src, float* dst, int taps, int a, int b, vcg_stream_t stream);
+
+/* ---- BatchNormalization (+PReLU/LeakyReLU, +Add): model.py:20-25,284-285,840-841;
+ *      instance norm is the north_star extension ------------------ */
+/* per-channel (batch) or per-(n,c) (instance) mean and biased variance of x[n,c,hw].
+ * mean/var: [c] (batch) or [n*c] (instance).  ws: vcg_norm_stats_workspace_bytes. */
+size_t vcg_norm_stats_workspace_bytes(int n, int c, int hw, int mode);
+int vcg_norm_stats(const float* x, int n, int c, int hw, int mode, float* mean, float* var,
+                   void* ws, size_t ws_bytes, vcg_stream_t stream);
+/* scale = gamma*rsqrt(var+eps), shift = beta - mean*scale ; gamma/beta may be NULL (1/0);
+ * moving_* (optional): moving = moving*momentum + batch*(1-momentum), var corrected by
+ * count/(count-1) when unbiased_count>1.  count entries = c or n*c. */
+int vcg_norm_finalize(const float* mean, const float* var, const float* gamma, const float* beta, int c,
+                      int rows, float eps, float* scale, float* shift, float* invstd,
+                      float* moving_mean, float* moving_var, float momentum, int unbiased_count,
+                      vcg_stream_t stream);
+/* y = act(x*scale + shift) + residual ; scale/shift indexed [c] (rows==1) or [n*c] */
+int vcg_norm_act_fwd(const float* x, int n, int c, int hw, const float* scale, const float* shift,
+                     int per_sample, int act, float act_alpha, const float* prelu_alpha,
+                     const float* residual, float* y, vcg_stream_t stream);
+/* backward of y = act(z), z = gamma*xhat+beta, xhat=(x-mean)*invstd:
+ *   pass 1 (reduce):  sum_dz, sum_dz_xhat per channel (or per (n,c)), dalpha per channel
+ *   pass 2 (apply):   dx = scale*(dz - sum_dz/M - xhat*sum_dz_xhat/M)      (training statistics)
+ *                or   dx = scale*dz                                          (frozen statistics)
+ * dgamma[c] = sum_dz_xhat, dbeta[c] = sum_dz (summed over n for instance mode). */
+size_t vcg_norm_act_bwd_workspace_bytes(int n, int c, int hw, int mode);
+int vcg_norm_act_bwd(const float* x, const float* dy, int n, int c, int hw, int mode,
+                     const float* mean, const float* invstd, const float* gamma, const float* beta,
+                     int act, float act_alpha, const float* prelu_alpha, int use_batch_stats,
+                     float* dx, float* dgamma, float* dbeta, float* dprelu_alpha,
+                     void* ws, size_t ws_bytes, vcg_stream_t stream);
+
+/* ---- plain activations: PReLU after 'initial/conv' (model.py:276), LeakyReLU (:73), tanh (:291) */
+/* dx = dy * act'(.) where the derivative is evaluated from the saved OUTPUT y (tanh, lrelu) or the
+ * saved INPUT x (prelu).  dprelu_alpha[c] (optional) accumulates sum dy*min(x,0). */
+size_t vcg_act_bwd_workspace_bytes(int n, int c, int hw);
+int vcg_act_bwd(const float* saved, const float* dy, int n, int c, int hw, int act, float act_alpha,
+                const float* prelu_alpha, float* dx, float* dprelu_alpha, void* ws, size_t ws_bytes,
+                vcg_stream_t stream);
+/* out[c] = sum over n,hw of x */
+size_t vcg_channel_sum_workspace_bytes(int n, int c, int hw);
+int vcg_channel_sum(const float* x, int n, int c, int hw, float* out, void* ws, size_t ws_bytes,
+                    vcg_stream_t stream);
+
+/* ---- Dense: model.py:876,880,884 -------------------------------------------------------------- */
+int vcg_dense_fwd(const float* x, const float* w_io, const float* bias, float* y, int batch, int in,
+                  int out, vcg_stream_t stream);
+int vcg_dense_dgrad(const float* dy, const float* w_io, float* dx, int batch, int in, int out,
+                    vcg_stream_t stream);
+int vcg_dense_wgrad(const float* x, const float* dy, float* dw_io, float* dbias, int batch, int in,
+                    int out, vcg_stream_t stream);
+
+/* ---- losses: model.py:159-160, 215-261; pixel term of model.py:137,157 ------------------------ */
+/* out[0] = mean(x) over count elements (deterministic two-stage) */
+size_t vcg_mean_reduce_workspace_bytes(size_t count);
+int vcg_mean_reduce(const float* x, size_t count, float* out, void* ws, size_t ws_bytes, vcg_stream_t stream);
+/* content loss value (out[0]) and gradient d/dpred scaled by grad_scale/count */
+int vcg_pixel_loss(const float* pred, const float* target, size_t count, int kind, float grad_scale,
+                   float* out, float* dpred, void* ws, size_t ws_bytes, vcg_stream_t stream);
+/* y = value everywhere (broadcast gradient of a mean) */
+int vcg_fill(float* y, size_t count, float value, vcg_stream_t stream);
+/* y = a*x + b*y */
+int vcg_axpby(const float* x, float* y, size_t count, float a, float b, vcg_stream_t stream);
+
+/* ---- Adam(): keras.optimizers.Adam defaults, model.py:1026,1066,1130 -------------------------- */
+/* multi-tensor update over one flat parameter buffer; lr_t = lr*sqrt(1-b2^t)/(1-b1^t) is computed
+ * by the caller; p -= lr_t * m / (sqrt(v) + eps) */
+int vcg_adam_keras_multi(float* p, const float* g, float* m, float* v, size_t count, float lr_t,
+                         float beta_1, float beta_2, float eps, vcg_stream_t stream);
+
+/* ---- frame edge: upscaling/upscaler/data.py:253-270 ------------------------------------------- */
+/* uint8 NHWC -> fp32 NCHW, v/127.5 - 1 */
+int vcg_frames_u8_to_nchw(const uint8_t* src, float* dst, int n, int h, int w, int c, vcg_stream_t stream);
+/* fp32 NCHW -> uint8 NHWC, uint8(around((a+1)*127.5)) */
+int vcg_nchw_to_frames_u8(const float* src, uint8_t* dst, int n, int h, int w, int c, vcg_stream_t stream);
+int vcg_nhwc_to_nchw(const float* src, float* dst, int n, int h, int w, int c, vcg_stream_t stream);
+int vcg_nchw_to_nhwc(const float* src, float* dst, int n, int h, int w, int c, vcg_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VCG_H */

@@ -1,0 +1,177 @@
+"""ORACLE -- TEST INFRASTRUCTURE ONLY.  PARITY UNPINNED.
+
+CPU restatement (torch CPU, fp32 or fp64) of the Keras 2.2.x / TF 1.14 layer semantics that the
+reference's hot path instantiates (reference imports: upscaling/upscaler/model.py:1-11).  Only
+``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import this
+package; the product path (``video-cycle_gan-upscaling_amd/``) never does.
+
+"Parity unpinned": the reference holds no numeric golden vectors for this path and Keras/TF are not
+installable here, so these functions are pinned only by
+  * the shape / parameter-count known answers of the reference's notebooks (SURVEY.md Appendix C,
+    checked in tests/test_oracle_known_answers.py),
+  * adjoint / finite-difference identities and cross-checks against torch.nn.functional
+    (tests/test_oracle_identities.py).
+
+Layout conventions: activations are NHWC at the API edge and NCHW inside
+these functions; kernels keep Keras' own layouts --
+  Conv2D kernel          (kh, kw, in, out)   "HWIO"
+  Conv2DTranspose kernel (kh, kw, out, in)   "HWOI"
+  Dense kernel           (in, out)
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+BN_EPS = 1e-3        # keras.layers.BatchNormalization default epsilon
+BN_MOMENTUM = 0.99   # keras.layers.BatchNormalization default momentum
+
+
+# ----------------------------------------------------------------------------------------------
+# padding arithmetic (TF "SAME"): SURVEY.md Appendix A, pinned by cnn_test.ipynb cell 12
+# ----------------------------------------------------------------------------------------------
+def same_pads(size, k, s):
+    """TF SAME: out = ceil(in/s); total = max((out-1)*s + k - in, 0); before = total//2."""
+    out = -(-size // s)
+    total = max((out - 1) * s + k - size, 0)
+    before = total // 2
+    return out, before, total - before
+
+
+def conv2d(x, w_hwio, b, stride=1, padding="same"):
+    """keras.layers.Conv2D forward. x: [N,C,H,W]; w: (kh,kw,in,out); padding 'same' | 'valid' | int.
+
+    An int padding p is symmetric explicit zero padding (used only by the PatchGAN extension,
+    which has no reference counterpart -- SURVEY.md section 8 row a11)."""
+    kh, kw = w_hwio.shape[0], w_hwio.shape[1]
+    w = w_hwio.permute(3, 2, 0, 1)                       # -> (out, in, kh, kw)
+    if padding == "same":
+        _, pt, pb = same_pads(x.shape[2], kh, stride)
+        _, pl, pr = same_pads(x.shape[3], kw, stride)
+    elif padding == "valid":
+        pt = pb = pl = pr = 0
+    else:
+        pt = pb = pl = pr = int(padding)
+    x = F.pad(x, (pl, pr, pt, pb))
+    return F.conv2d(x, w, b, stride=stride)
+
+
+def conv2d_transpose_same(x, w_hwoi, b, stride=2):
+    """keras.layers.Conv2DTranspose(padding='same') forward (reference: model.py:72).
+
+    out = in*stride; equals the full transposed convolution (length (in-1)*s + k) cropped by
+    before = floor((k-s)/2), after = ceil((k-s)/2)  (SURVEY.md Appendix A)."""
+    kh, kw = w_hwoi.shape[0], w_hwoi.shape[1]
+    w = w_hwoi.permute(3, 2, 0, 1)                       # (in, out, kh, kw) == torch conv_transpose
+    full = F.conv_transpose2d(x, w, None, stride=stride)
+    oh, ow = x.shape[2] * stride, x.shape[3] * stride
+    ct = max(kh - stride, 0) // 2
+    cl = max(kw - stride, 0) // 2
+    y = full[:, :, ct:ct + oh, cl:cl + ow]
+    if b is not None:
+        y = y + b.view(1, -1, 1, 1)
+    return y
+
+
+def dense(x, w_io, b):
+    """keras.layers.Dense: x [N,in] @ (in,out) + b."""
+    y = x @ w_io
+    return y + b if b is not None else y
+
+
+def flatten_nhwc(x):
+    """keras.layers.Flatten of an NHWC tensor is (h, w, c)-major; x is NCHW here."""
+    return x.permute(0, 2, 3, 1).reshape(x.shape[0], -1)
+
+
+# ----------------------------------------------------------------------------------------------
+# normalisation
+# ----------------------------------------------------------------------------------------------
+def batchnorm(x, gamma, beta, moving_mean, moving_var, training, eps=BN_EPS, momentum=BN_MOMENTUM):
+    """keras.layers.BatchNormalization (axis=-1 in NHWC == channel dim 1 here; 2-D input: dim 1).
+
+    training: normalise with the biased batch variance.  Moving statistics are updated as
+    ``moving*momentum + batch*(1-momentum)``; for 4-D inputs Keras' TF backend takes the fused path
+    (tf.nn.fused_batch_norm) whose returned variance carries Bessel's correction, for 2-D inputs it
+    takes the tf.nn.moments path (biased) -- SURVEY.md Appendix A.
+    Returns (y, new_moving_mean, new_moving_var)."""
+    if x.dim() == 4:
+        axes, shape = (0, 2, 3), (1, -1, 1, 1)
+    else:
+        axes, shape = (0,), (1, -1)
+    if training:
+        mean = x.mean(dim=axes)
+        var = x.var(dim=axes, unbiased=False)
+        m = x.numel() // x.shape[1]
+        var_upd = var * (m / max(m - 1, 1)) if x.dim() == 4 else var
+        new_mm = moving_mean * momentum + mean.detach() * (1 - momentum)
+        new_mv = moving_var * momentum + var_upd.detach() * (1 - momentum)
+    else:
+        mean, var = moving_mean, moving_var
+        new_mm, new_mv = moving_mean, moving_var
+    y = (x - mean.view(shape)) * torch.rsqrt(var.view(shape) + eps)
+    if gamma is not None:
+        y = y * gamma.view(shape)
+    if beta is not None:
+        y = y + beta.view(shape)
+    return y, new_mm, new_mv
+
+
+def instancenorm(x, gamma=None, beta=None, eps=1e-5):
+    """Instance normalisation over (H, W) per (n, c) -- north_star extension, no reference
+    counterpart; eps follows the canonical CycleGAN (1e-5)."""
+    mean = x.mean(dim=(2, 3), keepdim=True)
+    var = x.var(dim=(2, 3), unbiased=False, keepdim=True)
+    y = (x - mean) * torch.rsqrt(var + eps)
+    if gamma is not None:
+        y = y * gamma.view(1, -1, 1, 1)
+    if beta is not None:
+        y = y + beta.view(1, -1, 1, 1)
+    return y
+
+
+# ----------------------------------------------------------------------------------------------
+# activations (reference: model.py:21,66,73,276,841)
+# ----------------------------------------------------------------------------------------------
+def prelu(x, alpha):
+    """PReLU(shared_axes=[1,2]): max(x,0) + alpha_c * min(x,0)."""
+    a = alpha.view(1, -1, 1, 1) if x.dim() == 4 else alpha.view(1, -1)
+    return torch.clamp(x, min=0) + a * torch.clamp(x, max=0)
+
+
+def leaky_relu(x, alpha):
+    return torch.where(x >= 0, x, x * alpha)
+
+
+def head_activation(x, name):
+    """Optional discriminator output squashing (reference: model.py:885-892) and GanLosses
+    loss_activation (model.py:172-181)."""
+    if name == "sigmoid":
+        return torch.sigmoid(x)
+    if name == "log-sigm":
+        return torch.log(torch.sigmoid(x))
+    if name == "tanh":
+        return torch.tanh(x)
+    if name == "bi-log":
+        return (x / (1 + x.abs())) * torch.log(x.abs() + 2)
+    return x
+
+
+# ----------------------------------------------------------------------------------------------
+# optimizer: keras.optimizers.Adam() defaults
+# ----------------------------------------------------------------------------------------------
+def adam_keras_step(p, g, m, v, t, lr=1e-3, beta_1=0.9, beta_2=0.999, eps=1e-7):
+    """One Keras-form Adam update; t counts from 1; eps sits OUTSIDE the bias correction."""
+    lr_t = lr * math.sqrt(1.0 - beta_2 ** t) / (1.0 - beta_1 ** t)
+    m_t = beta_1 * m + (1.0 - beta_1) * g
+    v_t = beta_2 * v + (1.0 - beta_2) * g * g
+    p_t = p - lr_t * m_t / (torch.sqrt(v_t) + eps)
+    return p_t, m_t, v_t
+
+
+def glorot_uniform(rng, shape, fan_in, fan_out):
+    """Keras default kernel initialiser: U(-l, l), l = sqrt(6/(fan_in+fan_out)).  rng is a
+    numpy RandomState (frozen stream)."""
+    import numpy as np
+    limit = math.sqrt(6.0 / (fan_in + fan_out))
+    return rng.uniform(-limit, limit, size=shape).astype(np.float32)

@@ -1,0 +1,246 @@
+"""ORACLE -- TEST INFRASTRUCTURE ONLY.  PARITY UNPINNED (see oracle/keras_ops.py header).
+
+CPU restatement of the reference's generator / discriminator topologies:
+  make_upscaler_orig              upscaling/upscaler/model.py:267-295  (blocks :15-27, :70-75)
+  make_discriminator_simple_512   upscaling/upscaler/model.py:836-896
+  make_discriminator_thin_512     upscaling/upscaler/model.py:901-961
+plus the north_star extension with no reference counterpart:
+  make_discriminator_patchgan_70  (C64-C128-C256 k4 s2, C512 k4 s1, C1 k4 s1, pad 1, LReLU 0.2)
+
+Weights live in a flat dict  "<keras layer name>/<keras weight name>" -> torch tensor, in Keras'
+own layouts, so the dict doubles as the weight-exchange format with the product.
+"""
+import math
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from . import keras_ops as K
+
+
+# ----------------------------------------------------------------------------------------------
+# weight construction (Keras defaults: Glorot-uniform kernels, zero bias, BN gamma=1 beta=0
+# moving_mean=0 moving_variance=1, PReLU alpha=0)
+# ----------------------------------------------------------------------------------------------
+def _conv_w(w, rng, name, kh, kw, cin, cout):
+    w[name + "/kernel"] = K.glorot_uniform(rng, (kh, kw, cin, cout), kh * kw * cin, kh * kw * cout)
+    w[name + "/bias"] = np.zeros((cout,), np.float32)
+
+
+def _convt_w(w, rng, name, kh, kw, cin, cout):
+    # Keras Conv2DTranspose kernel is (kh, kw, out, in); fan_in/fan_out as keras computes them for
+    # that shape: receptive*shape[-2] / receptive*shape[-1]
+    w[name + "/kernel"] = K.glorot_uniform(rng, (kh, kw, cout, cin), kh * kw * cout, kh * kw * cin)
+    w[name + "/bias"] = np.zeros((cout,), np.float32)
+
+
+def _dense_w(w, rng, name, cin, cout):
+    w[name + "/kernel"] = K.glorot_uniform(rng, (cin, cout), cin, cout)
+    w[name + "/bias"] = np.zeros((cout,), np.float32)
+
+
+def _bn_w(w, name, c):
+    w[name + "/gamma"] = np.ones((c,), np.float32)
+    w[name + "/beta"] = np.zeros((c,), np.float32)
+    w[name + "/moving_mean"] = np.zeros((c,), np.float32)
+    w[name + "/moving_variance"] = np.ones((c,), np.float32)
+
+
+def _prelu_w(w, name, c):
+    w[name + "/alpha"] = np.zeros((c,), np.float32)
+
+
+NON_TRAINABLE_SUFFIXES = ("/moving_mean", "/moving_variance")
+
+
+def is_trainable(name):
+    return not name.endswith(NON_TRAINABLE_SUFFIXES)
+
+
+def to_torch(w, dtype=torch.float32, requires_grad=False):
+    out = OrderedDict()
+    for k, v in w.items():
+        t = torch.tensor(np.asarray(v), dtype=dtype)
+        if requires_grad and is_trainable(k):
+            t.requires_grad_(True)
+        out[k] = t
+    return out
+
+
+# ----------------------------------------------------------------------------------------------
+# generator: make_upscaler_orig (model.py:267-295)
+# ----------------------------------------------------------------------------------------------
+def init_upscaler_orig(output_image_shape, kernel_size=5, filters=64, upscale_factor=4,
+                       res_block_num=16, seed=7):
+    rng = np.random.RandomState(seed)
+    k = kernel_size
+    w = OrderedDict()
+    _conv_w(w, rng, "initial/conv", 9, 9, output_image_shape[2], filters)
+    _prelu_w(w, "initial/prelu", filters)
+    for i in range(res_block_num):
+        n = "res_block/%d" % i
+        _conv_w(w, rng, n + "/conv_pre", k, k, filters, filters)
+        _bn_w(w, n + "/batch_norm_pre", filters)
+        _prelu_w(w, n + "/prelu", filters)
+        _conv_w(w, rng, n + "/conv_post", k, k, filters, filters)
+        _bn_w(w, n + "/batch_norm_post", filters)
+    _conv_w(w, rng, "prefinal/conv2d", k, k, filters, 64)         # 64 hard-coded: model.py:283
+    _bn_w(w, "prefinal/batch_norm", 64)
+    cin = 64
+    for i in range(int(math.log(upscale_factor, 2))):
+        _convt_w(w, rng, "upscaling/%d/block/conv_transp" % i, k, k, cin, 256)  # 256: model.py:288
+        cin = 256
+    _conv_w(w, rng, "final/conv", 9, 9, cin, 3)
+    return w
+
+
+def upscaler_orig_forward(w, x_nhwc, training, res_block_num, upscale_factor, taps=None):
+    """x_nhwc: [N,h,w,3] -> ([N,h*f,w*f,3], bn_updates).  ``training`` selects batch vs moving BN
+    statistics (Keras learning phase: predict=0, train_on_batch=1).  ``taps`` (optional dict)
+    receives named NCHW intermediates for kernel-level parity tests."""
+    upd = OrderedDict()
+
+    def bn(x, name):
+        y, mm, mv = K.batchnorm(x, w[name + "/gamma"], w[name + "/beta"], w[name + "/moving_mean"],
+                                w[name + "/moving_variance"], training)
+        if training:
+            upd[name + "/moving_mean"], upd[name + "/moving_variance"] = mm, mv
+        return y
+
+    def conv(x, name, stride=1):
+        return K.conv2d(x, w[name + "/kernel"], w[name + "/bias"], stride, "same")
+
+    def tap(name, t):
+        if taps is not None:
+            taps[name] = t
+        return t
+
+    x = x_nhwc.permute(0, 3, 1, 2)
+    m = tap("initial/prelu", K.prelu(tap("initial/conv", conv(x, "initial/conv")), w["initial/prelu/alpha"]))
+    skip = m
+    for i in range(res_block_num):
+        n = "res_block/%d" % i
+        gen = m
+        m = tap(n + "/conv_pre", conv(m, n + "/conv_pre"))
+        m = bn(m, n + "/batch_norm_pre")
+        m = tap(n + "/prelu", K.prelu(m, w[n + "/prelu/alpha"]))
+        m = tap(n + "/conv_post", conv(m, n + "/conv_post"))
+        m = bn(m, n + "/batch_norm_post")
+        m = tap(n + "/final_add", gen + m)
+    m = conv(m, "prefinal/conv2d")
+    m = bn(m, "prefinal/batch_norm")
+    m = tap("prefinal/tanh", skip + m)                            # Add misnamed in model.py:285
+    for i in range(int(math.log(upscale_factor, 2))):
+        n = "upscaling/%d/block" % i
+        m = K.conv2d_transpose_same(m, w[n + "/conv_transp/kernel"], w[n + "/conv_transp/bias"], 2)
+        m = tap(n + "/leaky_relu", K.leaky_relu(m, 0.2))
+    m = tap("final/conv", conv(m, "final/conv"))
+    m = torch.tanh(m)
+    return m.permute(0, 2, 3, 1), upd
+
+
+# ----------------------------------------------------------------------------------------------
+# discriminators
+# ----------------------------------------------------------------------------------------------
+_SIMPLE_FILTERS = (64, 128, 256, 512, 512, 512, 512, 512, 512)     # model.py:839-871
+_THIN_FILTERS = (64,) + (128,) * 8                                      # model.py:904-936
+
+
+def _disc_out_hw(h, w, nblocks):
+    for i in range(1, nblocks):
+        h, w = -(-h // 2), -(-w // 2)
+    return h, w
+
+
+def init_discriminator_512(input_shape, variant="simple", seed=11):
+    filters = _SIMPLE_FILTERS if variant == "simple" else _THIN_FILTERS
+    rng = np.random.RandomState(seed)
+    w = OrderedDict()
+    cin = input_shape[2]
+    for i, f in enumerate(filters):
+        n = "discriminator/block_%d" % (i + 1)
+        _conv_w(w, rng, n + "/Conv2d", 3, 3, cin, f)
+        _bn_w(w, n + "/BatchNorm", f)
+        cin = f
+    h, ww = _disc_out_hw(input_shape[0], input_shape[1], len(filters))
+    _dense_w(w, rng, "discriminator/final/Dense_1", h * ww * cin, 1024)
+    _bn_w(w, "discriminator/final/BatchNorm_1", 1024)
+    _dense_w(w, rng, "discriminator/final/Dense_2", 1024, 32)
+    _bn_w(w, "discriminator/final/BatchNorm_2", 32)
+    _dense_w(w, rng, "discriminator/final/Dense_3", 32, 1)
+    return w
+
+
+def discriminator_512_forward(w, x_nhwc, training, activation="none", taps=None):
+    """make_discriminator_simple_512 / _thin_512 forward: [N,H,W,3] -> ([N,1], bn_updates)."""
+    upd = OrderedDict()
+
+    def bn(x, name):
+        y, mm, mv = K.batchnorm(x, w[name + "/gamma"], w[name + "/beta"], w[name + "/moving_mean"],
+                                w[name + "/moving_variance"], training)
+        if training:
+            upd[name + "/moving_mean"], upd[name + "/moving_variance"] = mm, mv
+        return y
+
+    m = x_nhwc.permute(0, 3, 1, 2)
+    i = 1
+    while ("discriminator/block_%d/Conv2d/kernel" % i) in w:
+        n = "discriminator/block_%d" % i
+        m = K.conv2d(m, w[n + "/Conv2d/kernel"], w[n + "/Conv2d/bias"], 1 if i == 1 else 2, "same")
+        m = bn(m, n + "/BatchNorm")
+        m = K.leaky_relu(m, 0.1)
+        if taps is not None:
+            taps[n + "/LeakyReLU"] = m
+        i += 1
+    m = K.flatten_nhwc(m)
+    for j in (1, 2):
+        m = K.dense(m, w["discriminator/final/Dense_%d/kernel" % j], w["discriminator/final/Dense_%d/bias" % j])
+        m = bn(m, "discriminator/final/BatchNorm_%d" % j)
+        m = K.leaky_relu(m, 0.1)
+    m = K.dense(m, w["discriminator/final/Dense_3/kernel"], w["discriminator/final/Dense_3/bias"])
+    return K.head_activation(m, activation), upd
+
+
+_PATCH_SPEC = ((64, 2, None), (128, 2, "norm"), (256, 2, "norm"), (512, 1, "norm"), (1, 1, "last"))
+
+
+def init_discriminator_patchgan_70(input_shape, norm="instance", seed=11):
+    rng = np.random.RandomState(seed)
+    w = OrderedDict()
+    cin = input_shape[2]
+    for i, (f, s, kind) in enumerate(_PATCH_SPEC):
+        n = "discriminator/block_%d" % (i + 1)
+        _conv_w(w, rng, n + "/Conv2d", 4, 4, cin, f)
+        if kind == "norm" and norm == "batch":
+            _bn_w(w, n + "/BatchNorm", f)
+        cin = f
+    return w
+
+
+def discriminator_patchgan_70_forward(w, x_nhwc, training, activation="none", norm="instance", taps=None):
+    """70x70 PatchGAN: [N,H,W,3] -> ([N,H',W',1], bn_updates); 512x512 -> 62x62."""
+    upd = OrderedDict()
+    m = x_nhwc.permute(0, 3, 1, 2)
+    for i, (f, s, kind) in enumerate(_PATCH_SPEC):
+        n = "discriminator/block_%d" % (i + 1)
+        m = K.conv2d(m, w[n + "/Conv2d/kernel"], w[n + "/Conv2d/bias"], s, 1)
+        if kind == "norm":
+            if norm == "instance":
+                m = K.instancenorm(m)
+            else:
+                bnn = n + "/BatchNorm"
+                m, mm, mv = K.batchnorm(m, w[bnn + "/gamma"], w[bnn + "/beta"], w[bnn + "/moving_mean"],
+                                        w[bnn + "/moving_variance"], training)
+                if training:
+                    upd[bnn + "/moving_mean"], upd[bnn + "/moving_variance"] = mm, mv
+        if kind != "last":
+            m = K.leaky_relu(m, 0.2)
+            if taps is not None:
+                taps[n + "/LeakyReLU"] = m
+    m = K.head_activation(m, activation)
+    return m.permute(0, 2, 3, 1), upd
+
+
+def count_params(w):
+    return int(sum(int(np.prod(v.shape)) for v in w.values()))

@@ -1,0 +1,269 @@
+"""GPU parity of every C-ABI kernel family against the CPU oracle (oracle/keras_ops.py) on the same
+seeded inputs.  Tolerance: 1e-3 max-norm relative (north_star: "within 1e-3 rel fp32"); the fp32 MFMA
+path is an exact fp32 FMA chain so observed errors are ~1e-6 (written to gpurun_out/parity_report.txt)."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err, report
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3
+
+
+def _standalone(rt, layer, seed=0, scale_bias=True):
+    from upscaler import _engine as E
+    ps = E.ParamStore()
+    layer.declare(ps)
+    ps.materialize(rt)
+    layer.bind(rt, ps)
+    rng = np.random.RandomState(seed)
+    w = layer.init_weights(rng)
+    for k in w:
+        if k.endswith(("/bias", "/beta", "/alpha")):
+            w[k] = rng.uniform(-0.5, 0.5, w[k].shape).astype(np.float32)
+        if k.endswith("/gamma"):
+            w[k] = rng.uniform(0.5, 1.5, w[k].shape).astype(np.float32)
+        if k.endswith("/moving_mean"):
+            w[k] = rng.uniform(-0.3, 0.3, w[k].shape).astype(np.float32)
+        if k.endswith("/moving_variance"):
+            w[k] = rng.uniform(0.5, 2.0, w[k].shape).astype(np.float32)
+    ps.set_weights(w)
+    return ps, {k: torch.tensor(v, dtype=torch.float64) for k, v in w.items()}
+
+
+CONV_CASES = [
+    # cin, cout, k, stride, padding, n, h, w
+    (64, 64, 3, 1, "same", 2, 16, 32),
+    (64, 64, 3, 1, "same", 1, 13, 45),       # ragged tile edges
+    (8, 64, 3, 1, "same", 1, 9, 33),
+    (64, 128, 3, 2, "same", 2, 16, 32),
+    (64, 128, 3, 2, "same", 1, 15, 31),      # odd size: TF SAME pads (1,1)
+    (128, 256, 3, 2, "same", 1, 8, 8),
+    (512, 512, 3, 2, "same", 2, 4, 4),
+    (512, 512, 3, 2, "same", 2, 2, 2),
+    (3, 64, 3, 1, "same", 2, 16, 40),
+    (3, 64, 9, 1, "same", 1, 16, 40),
+    (64, 64, 5, 1, "same", 1, 12, 34),
+    (256, 3, 9, 1, "same", 1, 20, 70),       # small-M kernel, 2 x-tiles
+    (64, 3, 9, 1, "same", 2, 9, 50),
+    (3, 64, 4, 2, 1, 1, 32, 32),             # PatchGAN
+    (64, 128, 4, 2, 1, 1, 16, 16),
+    (256, 512, 4, 1, 1, 1, 9, 9),
+    (512, 1, 4, 1, 1, 1, 10, 10),
+    (16, 1, 4, 1, 1, 2, 8, 70),
+]
+
+
+@pytest.mark.parametrize("cin,cout,k,stride,padding,n,h,w", CONV_CASES)
+def test_conv2d_fwd_dgrad_wgrad(rt, cin, cout, k, stride, padding, n, h, w):
+    from upscaler import _engine as E, _lib as L
+    from oracle import keras_ops as K
+    layer = E.Conv2D("c", cin, cout, k, stride, padding)
+    ps, wd = _standalone(rt, layer, seed=cin + cout + k)
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(n, cin, h, w, generator=g, dtype=torch.float64)
+    xr = x.clone().requires_grad_(True)
+    wk = wd["c/kernel"].clone().requires_grad_(True)
+    bk = wd["c/bias"].clone().requires_grad_(True)
+    yr = K.conv2d(xr, wk, bk, stride, padding)
+    dy = torch.randn(*yr.shape, generator=g, dtype=torch.float64)
+    (yr * dy).sum().backward()
+
+    xd = x.float().to(rt.device)
+    y, ctx = layer.forward(xd)
+    e_f = rel_err(y, yr)
+    dx = layer.backward(ctx, dy.float().to(rt.device), True, True, 0)
+    e_dx = rel_err(dx, xr.grad)
+    e_dw = rel_err(ps.grad("c/kernel"), wk.grad)
+    e_db = rel_err(ps.grad("c/bias"), bk.grad)
+    report("conv2d cin=%d cout=%d k=%d s=%d pad=%s n=%d %dx%d  fwd=%.2e dx=%.2e dw=%.2e db=%.2e"
+           % (cin, cout, k, stride, padding, n, h, w, e_f, e_dx, e_dw, e_db))
+    assert e_f < TOL and e_dx < TOL and e_dw < TOL and e_db < TOL
+
+    # residual-add epilogue of dgrad (used by the residual blocks' backward)
+    res = torch.randn(n, cin, h, w, generator=g, dtype=torch.float64)
+    dx2 = layer.backward(ctx, dy.float().to(rt.device), True, False, 0, dx_residual=res.float().to(rt.device))
+    assert rel_err(dx2, xr.grad + res) < TOL
+
+
+@pytest.mark.parametrize("act", ["lrelu", "tanh"])
+def test_conv2d_fused_activation(rt, act):
+    from upscaler import _engine as E, _lib as L
+    from oracle import keras_ops as K
+    code = {"lrelu": L.ACT_LRELU, "tanh": L.ACT_TANH}[act]
+    layer = E.Conv2D("c", 16, 64, 3, 1, "same", code, 0.2)
+    ps, wd = _standalone(rt, layer, seed=3)
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(2, 16, 10, 37, generator=g, dtype=torch.float64)
+    xr = x.clone().requires_grad_(True)
+    wk = wd["c/kernel"].clone().requires_grad_(True)
+    z = K.conv2d(xr, wk, wd["c/bias"], 1, "same")
+    yr = K.leaky_relu(z, 0.2) if act == "lrelu" else torch.tanh(z)
+    dy = torch.randn(*yr.shape, generator=g, dtype=torch.float64)
+    (yr * dy).sum().backward()
+    y, ctx = layer.forward(x.float().to(rt.device))
+    dx = layer.backward(ctx, dy.float().to(rt.device))
+    e = (rel_err(y, yr), rel_err(dx, xr.grad), rel_err(ps.grad("c/kernel"), wk.grad))
+    report("conv2d+%s fwd=%.2e dx=%.2e dw=%.2e" % ((act,) + e))
+    assert max(e) < TOL
+
+
+CONVT_CASES = [(64, 256, 3, 1, 8, 32), (64, 256, 3, 2, 7, 19), (256, 256, 3, 1, 6, 6), (64, 256, 5, 1, 9, 33),
+               (16, 64, 3, 1, 4, 40)]
+
+
+@pytest.mark.parametrize("cin,cout,k,n,h,w", CONVT_CASES)
+def test_conv_transpose2d(rt, cin, cout, k, n, h, w):
+    from upscaler import _engine as E, _lib as L
+    from oracle import keras_ops as K
+    layer = E.ConvT2D("t", cin, cout, k, L.ACT_LRELU, 0.2)
+    ps, wd = _standalone(rt, layer, seed=k)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(n, cin, h, w, generator=g, dtype=torch.float64)
+    xr = x.clone().requires_grad_(True)
+    wk = wd["t/kernel"].clone().requires_grad_(True)
+    bk = wd["t/bias"].clone().requires_grad_(True)
+    yr = K.leaky_relu(K.conv2d_transpose_same(xr, wk, bk, 2), 0.2)
+    dy = torch.randn(*yr.shape, generator=g, dtype=torch.float64)
+    (yr * dy).sum().backward()
+    y, ctx = layer.forward(x.float().to(rt.device))
+    dx = layer.backward(ctx, dy.float().to(rt.device))
+    e = (rel_err(y, yr), rel_err(dx, xr.grad), rel_err(ps.grad("t/kernel"), wk.grad), rel_err(ps.grad("t/bias"), bk.grad))
+    report("convT cin=%d cout=%d k=%d n=%d %dx%d fwd=%.2e dx=%.2e dw=%.2e db=%.2e" % ((cin, cout, k, n, h, w) + e))
+    assert max(e) < TOL
+
+
+NORM_CASES = [("batch", "prelu", 2, 64, 16, 32, True), ("batch", "none", 3, 64, 7, 9, True),
+              ("batch", "lrelu", 2, 128, 8, 8, False), ("instance", "lrelu", 2, 128, 12, 12, False),
+              ("batch", "lrelu", 8, 1024, 1, 1, False), ("batch", "prelu", 1, 64, 64, 64, True)]
+
+
+@pytest.mark.parametrize("norm,act,n,c,h,w,residual", NORM_CASES)
+def test_norm_act_fwd_bwd(rt, norm, act, n, c, h, w, residual):
+    from upscaler import _engine as E, _lib as L
+    from oracle import keras_ops as K
+    code = {"prelu": L.ACT_PRELU, "lrelu": L.ACT_LRELU, "none": L.ACT_NONE}[act]
+    layer = E.NormAct("bn", c, norm, code, 0.1, prelu_name="pr")
+    ps, wd = _standalone(rt, layer, seed=c)
+    g = torch.Generator().manual_seed(7)
+    dense = (h == 1 and w == 1)
+    shape = (n, c) if dense else (n, c, h, w)
+    x = torch.randn(*shape, generator=g, dtype=torch.float64) * 1.7 + 0.4
+    r = torch.randn(*shape, generator=g, dtype=torch.float64) if residual else None
+    xr = x.clone().requires_grad_(True)
+    leaf = {k: v.clone().requires_grad_(True) for k, v in wd.items()}
+
+    def ref(training):
+        if norm == "batch":
+            z, mm, mv = K.batchnorm(xr, leaf["bn/gamma"], leaf["bn/beta"], leaf["bn/moving_mean"], leaf["bn/moving_variance"], training)
+        else:
+            z, mm, mv = K.instancenorm(xr), None, None
+        if act == "prelu":
+            z = K.prelu(z, leaf["pr/alpha"])
+        elif act == "lrelu":
+            z = K.leaky_relu(z, 0.1)
+        return (z + r if residual else z), mm, mv
+
+    xd = x.float().to(rt.device)
+    rd = r.float().to(rt.device) if residual else None
+    # inference mode (moving statistics)
+    if norm == "batch":
+        y0, _ = layer.forward(xd, False, residual=rd)
+        assert rel_err(y0, ref(False)[0]) < TOL
+    yr, mm, mv = ref(True)
+    dy = torch.randn(*shape, generator=g, dtype=torch.float64)
+    (yr * dy).sum().backward()
+    y, ctx = layer.forward(xd, True, residual=rd)
+    dx = layer.backward(ctx, dy.float().to(rt.device))
+    errs = [rel_err(y, yr), rel_err(dx, xr.grad)]
+    if norm == "batch":
+        errs += [rel_err(ps.grad("bn/gamma"), leaf["bn/gamma"].grad), rel_err(ps.grad("bn/beta"), leaf["bn/beta"].grad),
+                 rel_err(ps["bn/moving_mean"], mm), rel_err(ps["bn/moving_variance"], mv)]
+    if act == "prelu":
+        errs.append(rel_err(ps.grad("pr/alpha"), leaf["pr/alpha"].grad))
+    report("norm=%s act=%s n=%d c=%d %dx%d res=%s errs=%s" % (norm, act, n, c, h, w, residual, ["%.1e" % e for e in errs]))
+    assert max(errs) < TOL
+
+
+def test_plain_prelu(rt):
+    from upscaler import _engine as E, _lib as L
+    from oracle import keras_ops as K
+    layer = E.NormAct("op", 64, None, L.ACT_PRELU, prelu_name="pr")
+    ps, wd = _standalone(rt, layer, seed=1)
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 64, 9, 20, generator=g, dtype=torch.float64)
+    xr = x.clone().requires_grad_(True)
+    al = wd["pr/alpha"].clone().requires_grad_(True)
+    yr = K.prelu(xr, al)
+    dy = torch.randn(*yr.shape, generator=g, dtype=torch.float64)
+    (yr * dy).sum().backward()
+    y, ctx = layer.forward(x.float().to(rt.device), True)
+    dx = layer.backward(ctx, dy.float().to(rt.device))
+    assert max(rel_err(y, yr), rel_err(dx, xr.grad), rel_err(ps.grad("pr/alpha"), al.grad)) < TOL
+
+
+@pytest.mark.parametrize("b,cin,cout", [(8, 2048, 1024), (3, 1024, 32), (8, 32, 1), (2, 77, 130)])
+def test_dense(rt, b, cin, cout):
+    from upscaler import _engine as E
+    from oracle import keras_ops as K
+    layer = E.Dense("d", cin, cout)
+    ps, wd = _standalone(rt, layer, seed=cout)
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(b, cin, generator=g, dtype=torch.float64)
+    xr = x.clone().requires_grad_(True)
+    wk = wd["d/kernel"].clone().requires_grad_(True)
+    bk = wd["d/bias"].clone().requires_grad_(True)
+    yr = K.dense(xr, wk, bk)
+    dy = torch.randn(*yr.shape, generator=g, dtype=torch.float64)
+    (yr * dy).sum().backward()
+    y, ctx = layer.forward(x.float().to(rt.device))
+    dx = layer.backward(ctx, dy.float().to(rt.device))
+    e = (rel_err(y, yr), rel_err(dx, xr.grad), rel_err(ps.grad("d/kernel"), wk.grad), rel_err(ps.grad("d/bias"), bk.grad))
+    report("dense b=%d %d->%d fwd=%.2e dx=%.2e dw=%.2e db=%.2e" % ((b, cin, cout) + e))
+    assert max(e) < TOL
+
+
+def test_adam_losses_layout(rt):
+    from upscaler import _engine as E, _lib as L
+    from oracle import keras_ops as K
+    lib = rt.lib
+    g = torch.Generator().manual_seed(4)
+    n = 100003
+    p, gr, m, v = (torch.randn(n, generator=g, dtype=torch.float64) for _ in range(4))
+    v = v.abs()
+    pr, mr, vr = K.adam_keras_step(p, gr, m, v, 3)
+    pd, gd, md, vd = (t.float().to(rt.device) for t in (p, gr, m, v))
+    import math
+    lr_t = 1e-3 * math.sqrt(1 - 0.999 ** 3) / (1 - 0.9 ** 3)
+    L.check(lib.vcg_adam_keras_multi(pd.data_ptr(), gd.data_ptr(), md.data_ptr(), vd.data_ptr(), n, lr_t, 0.9, 0.999, 1e-7, rt.stream), "adam")
+    assert max(rel_err(pd, pr), rel_err(md, mr), rel_err(vd, vr)) < 1e-5
+    # pixel loss
+    a, b = torch.randn(2, 3, 17, 19, generator=g, dtype=torch.float64), torch.randn(2, 3, 17, 19, generator=g, dtype=torch.float64)
+    for kind, code in (("mse", L.LOSS_MSE), ("mae", L.LOSS_MAE)):
+        ar = a.clone().requires_grad_(True)
+        lv = ((ar - b) ** 2).mean() if kind == "mse" else (ar - b).abs().mean()
+        (0.7 * lv).backward()
+        out, da = rt.empty(1), rt.empty(*a.shape)
+        ws, wsn = rt.workspace(lib.vcg_mean_reduce_workspace_bytes(a.numel()))
+        L.check(lib.vcg_pixel_loss(a.float().to(rt.device).data_ptr(), b.float().to(rt.device).data_ptr(), a.numel(), code, 0.7,
+                                   out.data_ptr(), da.data_ptr(), ws, wsn, rt.stream), "pixel_loss")
+        assert abs(out.item() - lv.item()) < 1e-5 * abs(lv.item()) + 1e-7
+        assert rel_err(da, ar.grad) < 1e-5
+    # layout + uint8 edge
+    from upscaler import data as D
+    from oracle import data as OD
+    u8 = torch.randint(0, 256, (2, 9, 11, 3), generator=g, dtype=torch.uint8)
+    dev = D.frames_u8_to_device(u8)
+    ref = torch.tensor(OD.convert_uint8_to_array(u8.numpy())).permute(0, 3, 1, 2).float()
+    assert torch.equal(dev.cpu(), ref)
+    back = D.device_to_frames_u8(dev).cpu()
+    assert torch.equal(back, u8)
+    xs = torch.rand(3, 8, 8, 3, generator=g) * 2 - 1
+    q = D.device_to_frames_u8(E.to_device_nchw(rt, xs)).cpu().numpy()
+    assert np.array_equal(q, OD.convert_array_to_uint8(xs.numpy().astype(np.float32)))
+    assert torch.equal(E.to_nhwc(rt, E.to_device_nchw(rt, xs)).cpu(), xs)
+    m = E.mean_scalar(rt, dev)
+    assert abs(m.item() - ref.double().mean().item()) < 1e-6

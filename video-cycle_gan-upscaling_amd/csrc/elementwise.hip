@@ -1,0 +1,361 @@
+// HBM-bound helper kernels of the train step: activation backward, per-channel sums (bias
+// gradients), loss reductions, Keras-form Adam, frame-edge layout/value conversion, per-tap kernel
+// transposes.  Reference call sites are quoted in include/vcg.h next to each entry point.
+#include "vcg_common.hpp"
+
+namespace {
+
+constexpr int kSumSplitMax = 64;
+
+inline int pick_split_cs(int c, size_t per_channel) {
+    int s = 1;
+    while (s < kSumSplitMax && (size_t)c * s < 1024 && per_channel / (s * 2) >= 2048) s *= 2;
+    return s;
+}
+
+// ---- activation backward (+ optional PReLU slope gradient partials) ---------------------------------
+__global__ __launch_bounds__(256) void act_bwd_kernel(const float* saved, const float* dy, int n, int c, int hw,
+                                                      int act, float act_alpha, const float* prelu, float* dx,
+                                                      float* part /* [n*c][gridDim.x] or null */) {
+    __shared__ float red[4];
+    const int plane = blockIdx.y;
+    const int ch = plane % c;
+    const float al = (act == VCG_ACT_PRELU) ? prelu[ch] : act_alpha;
+    const size_t base = (size_t)plane * hw;
+    float v[1] = {0.f};
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < hw; i += gridDim.x * 256) {
+        const float s = saved[base + i], d = dy[base + i];
+        float g;
+        if (act == VCG_ACT_TANH) g = 1.f - s * s;                 // saved = output
+        else if (act == VCG_ACT_LRELU) g = s >= 0.f ? 1.f : al;   // saved = output (slope > 0 keeps the sign)
+        else if (act == VCG_ACT_PRELU) { g = s > 0.f ? 1.f : al; v[0] += d * fminf(s, 0.f); }  // saved = input
+        else g = 1.f;
+        dx[base + i] = d * g;
+    }
+    if (part) {
+        block_sum<1>(v, red);
+        if (threadIdx.x == 0) part[(size_t)plane * gridDim.x + blockIdx.x] = v[0];
+    }
+}
+
+// out[ch] = sum_{n, k} part[(n*c+ch)*per + k]
+__global__ void plane_partial_final_kernel(const float* part, int n, int c, int per, float* out) {
+    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch >= c) return;
+    float s = 0.f;
+    for (int nn = 0; nn < n; ++nn)
+        for (int k = 0; k < per; ++k) s += part[((size_t)nn * c + ch) * per + k];
+    out[ch] = s;
+}
+
+// ---- per-channel sum over (n, hw) --------------------------------------------------------------------
+__global__ __launch_bounds__(256) void channel_sum_partial_kernel(const float* x, int n, int c, int hw, int split,
+                                                                  float* part /* [c][split] */) {
+    __shared__ float red[4];
+    const int ch = blockIdx.x / split, s = blockIdx.x % split;
+    const size_t M = (size_t)n * hw;
+    const size_t per = (M + split - 1) / split;
+    const size_t beg = (size_t)s * per, end = beg + per < M ? beg + per : M;
+    float v[1] = {0.f};
+    if (beg < end) {
+        const size_t hws = (size_t)hw;
+        const size_t n0 = beg / hws, n1 = (end - 1) / hws;
+        for (size_t nn = n0; nn <= n1; ++nn) {
+            const size_t lo = (beg > nn * hws ? beg : nn * hws) - nn * hws;
+            const size_t hi = (end < (nn + 1) * hws ? end : (nn + 1) * hws) - nn * hws;
+            const float* xp = x + (nn * c + ch) * hws;
+            for (size_t r = lo + threadIdx.x; r < hi; r += 256) v[0] += xp[r];
+        }
+    }
+    block_sum<1>(v, red);
+    if (threadIdx.x == 0) part[(size_t)ch * split + s] = v[0];
+}
+
+__global__ void channel_sum_final_kernel(const float* part, int c, int split, float* out) {
+    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch >= c) return;
+    float s = 0.f;
+    for (int k = 0; k < split; ++k) s += part[(size_t)ch * split + k];
+    out[ch] = s;
+}
+
+// ---- flat reductions ----------------------------------------------------------------------------------
+constexpr int kRedBlocks = 1024;
+
+__global__ __launch_bounds__(256) void sum_partial_kernel(const float* x, size_t count, float* part) {
+    __shared__ float red[4];
+    float v[1] = {0.f};
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (size_t)gridDim.x * 256) v[0] += x[i];
+    block_sum<1>(v, red);
+    if (threadIdx.x == 0) part[blockIdx.x] = v[0];
+}
+
+__global__ __launch_bounds__(256) void sum_final_kernel(const float* part, int nparts, float scale, float* out) {
+    __shared__ float red[4];
+    float v[1] = {0.f};
+    for (int i = threadIdx.x; i < nparts; i += 256) v[0] += part[i];
+    block_sum<1>(v, red);
+    if (threadIdx.x == 0) out[0] = v[0] * scale;
+}
+
+__global__ __launch_bounds__(256) void pixel_loss_kernel(const float* pred, const float* target, size_t count, int kind,
+                                                         float gscale, float* part, float* dpred) {
+    __shared__ float red[4];
+    float v[1] = {0.f};
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (size_t)gridDim.x * 256) {
+        const float d = pred[i] - target[i];
+        if (kind == VCG_LOSS_MSE) {
+            v[0] += d * d;
+            if (dpred) dpred[i] = 2.f * d * gscale;
+        } else {
+            v[0] += fabsf(d);
+            if (dpred) dpred[i] = (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) * gscale;
+        }
+    }
+    block_sum<1>(v, red);
+    if (threadIdx.x == 0) part[blockIdx.x] = v[0];
+}
+
+__global__ void fill_kernel(float* y, size_t count, float value) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < count) y[i] = value;
+}
+
+__global__ void axpby_kernel(const float* x, float* y, size_t count, float a, float b) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < count) y[i] = a * x[i] + (b == 0.f ? 0.f : b * y[i]);
+}
+
+// ---- Keras-form Adam over a flat buffer ---------------------------------------------------------------
+__global__ __launch_bounds__(256) void adam_kernel(float* p, const float* g, float* m, float* v, size_t count,
+                                                   float lr_t, float b1, float b2, float eps) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= count) return;
+    const float gi = g[i];
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    p[i] = p[i] - lr_t * mi / (sqrtf(vi) + eps);
+}
+
+// ---- layout / value conversion at the frame edge ------------------------------------------------------
+__global__ void u8_to_nchw_kernel(const uint8_t* src, float* dst, int n, int h, int w, int c) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;  // index in dst (NCHW)
+    const size_t total = (size_t)n * c * h * w;
+    if (i >= total) return;
+    const int x = (int)(i % w);
+    const int y = (int)((i / w) % h);
+    const int ch = (int)((i / ((size_t)w * h)) % c);
+    const size_t nn = i / ((size_t)w * h * c);
+    const uint8_t u = src[((nn * h + y) * w + x) * c + ch];
+    dst[i] = (float)((double)u / 127.5 - 1.0);               // data.py:266-270 computes in float64
+}
+
+__global__ void nchw_to_u8_kernel(const float* src, uint8_t* dst, int n, int h, int w, int c) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;  // index in dst (NHWC)
+    const size_t total = (size_t)n * c * h * w;
+    if (i >= total) return;
+    const int ch = (int)(i % c);
+    const int x = (int)((i / c) % w);
+    const int y = (int)((i / ((size_t)c * w)) % h);
+    const size_t nn = i / ((size_t)c * w * h);
+    const float a = src[((nn * c + ch) * h + y) * w + x];
+    float r = rintf((a + 1.f) * 127.5f);                     // np.around = round-half-even (data.py:254)
+    r = fminf(fmaxf(r, 0.f), 255.f);
+    dst[i] = (uint8_t)r;
+}
+
+__global__ void nhwc_to_nchw_kernel(const float* src, float* dst, int n, int h, int w, int c) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;  // dst index
+    const size_t total = (size_t)n * c * h * w;
+    if (i >= total) return;
+    const int x = (int)(i % w);
+    const int y = (int)((i / w) % h);
+    const int ch = (int)((i / ((size_t)w * h)) % c);
+    const size_t nn = i / ((size_t)w * h * c);
+    dst[i] = src[((nn * h + y) * w + x) * c + ch];
+}
+
+__global__ void nchw_to_nhwc_kernel(const float* src, float* dst, int n, int h, int w, int c) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;  // dst index
+    const size_t total = (size_t)n * c * h * w;
+    if (i >= total) return;
+    const int ch = (int)(i % c);
+    const int x = (int)((i / c) % w);
+    const int y = (int)((i / ((size_t)c * w)) % h);
+    const size_t nn = i / ((size_t)c * w * h);
+    dst[i] = src[((nn * c + ch) * h + y) * w + x];
+}
+
+// (taps, a, b) -> (taps, b, a), LDS-tiled 32x32 transpose
+__global__ __launch_bounds__(256) void kernel_transpose_kernel(const float* src, float* dst, int a, int b) {
+    __shared__ float tile[32][33];
+    const int t = blockIdx.z;
+    const int a0 = blockIdx.y * 32, b0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    const float* s = src + (size_t)t * a * b;
+    float* d = dst + (size_t)t * a * b;
+    for (int r = ty; r < 32; r += 8)
+        if (a0 + r < a && b0 + tx < b) tile[r][tx] = s[(size_t)(a0 + r) * b + b0 + tx];
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8)
+        if (b0 + r < b && a0 + tx < a) d[(size_t)(b0 + r) * a + a0 + tx] = tile[tx][r];
+}
+
+inline unsigned blocks_for(size_t count) { return (unsigned)((count + 255) / 256); }
+
+}  // namespace
+
+extern "C" {
+
+size_t vcg_act_bwd_workspace_bytes(int n, int c, int hw) { return (size_t)n * c * 64 * sizeof(float); }
+
+int vcg_act_bwd(const float* saved, const float* dy, int n, int c, int hw, int act, float act_alpha,
+                const float* prelu_alpha, float* dx, float* dprelu_alpha, void* ws, size_t ws_bytes,
+                vcg_stream_t stream) {
+    VCG_CHECK_PTR(saved); VCG_CHECK_PTR(dy); VCG_CHECK_PTR(dx);
+    if (n <= 0 || c <= 0 || hw <= 0 || (long)n * c > 65535) return VCG_E_SHAPE;
+    if (act == VCG_ACT_PRELU && prelu_alpha == nullptr) return VCG_E_NULL;
+    hipStream_t st = (hipStream_t)stream;
+    int gx = ceil_div(hw, 256 * 4);
+    if (gx > 64) gx = 64;
+    if (gx < 1) gx = 1;
+    float* part = nullptr;
+    if (dprelu_alpha) {
+        if (ws == nullptr || ws_bytes < vcg_act_bwd_workspace_bytes(n, c, hw)) return VCG_E_WORKSPACE;
+        part = (float*)ws;
+    }
+    hipLaunchKernelGGL(act_bwd_kernel, dim3(gx, (unsigned)(n * c)), dim3(256), 0, st, saved, dy, n, c, hw, act,
+                       act_alpha, prelu_alpha, dx, part);
+    VCG_LAUNCH_CHECK();
+    if (dprelu_alpha) {
+        hipLaunchKernelGGL(plane_partial_final_kernel, dim3(ceil_div(c, 256)), dim3(256), 0, st, (const float*)part, n,
+                           c, gx, dprelu_alpha);
+        VCG_LAUNCH_CHECK();
+    }
+    return VCG_OK;
+}
+
+size_t vcg_channel_sum_workspace_bytes(int n, int c, int hw) { return (size_t)c * kSumSplitMax * sizeof(float); }
+
+int vcg_channel_sum(const float* x, int n, int c, int hw, float* out, void* ws, size_t ws_bytes,
+                    vcg_stream_t stream) {
+    VCG_CHECK_PTR(x); VCG_CHECK_PTR(out); VCG_CHECK_PTR(ws);
+    if (n <= 0 || c <= 0 || hw <= 0) return VCG_E_SHAPE;
+    if (ws_bytes < vcg_channel_sum_workspace_bytes(n, c, hw)) return VCG_E_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const int split = pick_split_cs(c, (size_t)n * hw);
+    hipLaunchKernelGGL(channel_sum_partial_kernel, dim3(c * split), dim3(256), 0, st, x, n, c, hw, split, (float*)ws);
+    VCG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(channel_sum_final_kernel, dim3(ceil_div(c, 256)), dim3(256), 0, st, (const float*)ws, c, split,
+                       out);
+    VCG_LAUNCH_CHECK();
+    return VCG_OK;
+}
+
+size_t vcg_mean_reduce_workspace_bytes(size_t count) { return kRedBlocks * sizeof(float); }
+
+int vcg_mean_reduce(const float* x, size_t count, float* out, void* ws, size_t ws_bytes, vcg_stream_t stream) {
+    VCG_CHECK_PTR(x); VCG_CHECK_PTR(out); VCG_CHECK_PTR(ws);
+    if (count == 0) return VCG_E_SHAPE;
+    if (ws_bytes < kRedBlocks * sizeof(float)) return VCG_E_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    unsigned nb = blocks_for(count);
+    if (nb > kRedBlocks) nb = kRedBlocks;
+    hipLaunchKernelGGL(sum_partial_kernel, dim3(nb), dim3(256), 0, st, x, count, (float*)ws);
+    VCG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(sum_final_kernel, dim3(1), dim3(256), 0, st, (const float*)ws, (int)nb, 1.f / (float)count, out);
+    VCG_LAUNCH_CHECK();
+    return VCG_OK;
+}
+
+int vcg_pixel_loss(const float* pred, const float* target, size_t count, int kind, float grad_scale, float* out,
+                   float* dpred, void* ws, size_t ws_bytes, vcg_stream_t stream) {
+    VCG_CHECK_PTR(pred); VCG_CHECK_PTR(target); VCG_CHECK_PTR(out); VCG_CHECK_PTR(ws);
+    if (count == 0) return VCG_E_SHAPE;
+    if (kind != VCG_LOSS_MSE && kind != VCG_LOSS_MAE) return VCG_E_UNSUPPORTED;
+    if (ws_bytes < kRedBlocks * sizeof(float)) return VCG_E_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    unsigned nb = blocks_for(count);
+    if (nb > kRedBlocks) nb = kRedBlocks;
+    hipLaunchKernelGGL(pixel_loss_kernel, dim3(nb), dim3(256), 0, st, pred, target, count, kind,
+                       grad_scale / (float)count, (float*)ws, dpred);
+    VCG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(sum_final_kernel, dim3(1), dim3(256), 0, st, (const float*)ws, (int)nb, 1.f / (float)count, out);
+    VCG_LAUNCH_CHECK();
+    return VCG_OK;
+}
+
+int vcg_fill(float* y, size_t count, float value, vcg_stream_t stream) {
+    VCG_CHECK_PTR(y);
+    if (count == 0) return VCG_OK;
+    hipLaunchKernelGGL(fill_kernel, dim3(blocks_for(count)), dim3(256), 0, (hipStream_t)stream, y, count, value);
+    VCG_LAUNCH_CHECK();
+    return VCG_OK;
+}
+
+int vcg_axpby(const float* x, float* y, size_t count, float a, float b, vcg_stream_t stream) {
+    VCG_CHECK_PTR(x); VCG_CHECK_PTR(y);
+    if (count == 0) return VCG_OK;
+    hipLaunchKernelGGL(axpby_kernel, dim3(blocks_for(count)), dim3(256), 0, (hipStream_t)stream, x, y, count, a, b);
+    VCG_LAUNCH_CHECK();
+    return VCG_OK;
+}
+
+int vcg_adam_keras_multi(float* p, const float* g, float* m, float* v, size_t count, float lr_t, float beta_1,
+                         float beta_2, float eps, vcg_stream_t stream) {
+    VCG_CHECK_PTR(p); VCG_CHECK_PTR(g); VCG_CHECK_PTR(m); VCG_CHECK_PTR(v);
+    if (count == 0) return VCG_OK;
+    hipLaunchKernelGGL(adam_kernel, dim3(blocks_for(count)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, count, lr_t,
+                       beta_1, beta_2, eps);
+    VCG_LAUNCH_CHECK();
+    return VCG_OK;
+}
+
+int vcg_frames_u8_to_nchw(const uint8_t* src, float* dst, int n, int h, int w, int c, vcg_stream_t stream) {
+    VCG_CHECK_PTR(src); VCG_CHECK_PTR(dst);
+    if (n <= 0 || h <= 0 || w <= 0 || c <= 0) return VCG_E_SHAPE;
+    const size_t total = (size_t)n * h * w * c;
+    hipLaunchKernelGGL(u8_to_nchw_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, src, dst, n, h, w, c);
+    VCG_LAUNCH_CHECK();
+    return VCG_OK;
+}
+
+int vcg_nchw_to_frames_u8(const float* src, uint8_t* dst, int n, int h, int w, int c, vcg_stream_t stream) {
+    VCG_CHECK_PTR(src); VCG_CHECK_PTR(dst);
+    if (n <= 0 || h <= 0 || w <= 0 || c <= 0) return VCG_E_SHAPE;
+    const size_t total = (size_t)n * h * w * c;
+    hipLaunchKernelGGL(nchw_to_u8_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, src, dst, n, h, w, c);
+    VCG_LAUNCH_CHECK();
+    return VCG_OK;
+}
+
+int vcg_nhwc_to_nchw(const float* src, float* dst, int n, int h, int w, int c, vcg_stream_t stream) {
+    VCG_CHECK_PTR(src); VCG_CHECK_PTR(dst);
+    if (n <= 0 || h <= 0 || w <= 0 || c <= 0) return VCG_E_SHAPE;
+    const size_t total = (size_t)n * h * w * c;
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, src, dst, n, h, w, c);
+    VCG_LAUNCH_CHECK();
+    return VCG_OK;
+}
+
+int vcg_nchw_to_nhwc(const float* src, float* dst, int n, int h, int w, int c, vcg_stream_t stream) {
+    VCG_CHECK_PTR(src); VCG_CHECK_PTR(dst);
+    if (n <= 0 || h <= 0 || w <= 0 || c <= 0) return VCG_E_SHAPE;
+    const size_t total = (size_t)n * h * w * c;
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, src, dst, n, h, w, c);
+    VCG_LAUNCH_CHECK();
+    return VCG_OK;
+}
+
+int vcg_kernel_transpose(const float* src, float* dst, int taps, int a, int b, vcg_stream_t stream) {
+    VCG_CHECK_PTR(src); VCG_CHECK_PTR(dst);
+    if (taps <= 0 || a <= 0 || b <= 0 || taps > 65535) return VCG_E_SHAPE;
+    hipLaunchKernelGGL(kernel_transpose_kernel, dim3(ceil_div(b, 32), ceil_div(a, 32), taps), dim3(256), 0,
+                       (hipStream_t)stream, src, dst, a, b);
+    VCG_LAUNCH_CHECK();
+    return VCG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,59 @@
+// Shared device/host helpers for the gfx950 hot-path kernels (wave64, MFMA f32 32x32x2).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "vcg.h"
+
+#define VCG_CHECK_PTR(p) do { if ((p) == nullptr) return VCG_E_NULL; } while (0)
+#define VCG_LAUNCH_CHECK() do { hipError_t e__ = hipGetLastError(); if (e__ != hipSuccess) return (int)e__; } while (0)
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// v_mfma_f32_32x32x2_f32: A lane l holds A[i=l&31][k=l>>5]; B lane l holds B[k=l>>5][j=l&31];
+// D reg r of lane l is D[row=(r&3)+8*(r>>2)+4*(l>>5)][col=l&31]   (cdna_hip_programming.md section 3)
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ int mfma_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
+__device__ __forceinline__ float apply_act(float v, int act, float alpha) {
+    // alpha = LeakyReLU slope or the channel's PReLU slope
+    if (act == VCG_ACT_LRELU) return v >= 0.f ? v : v * alpha;
+    if (act == VCG_ACT_PRELU) return fmaxf(v, 0.f) + alpha * fminf(v, 0.f);
+    if (act == VCG_ACT_TANH) return tanhf(v);
+    return v;
+}
+
+// wave64 sum via DPP-free shuffles
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// block-wide sum of up to 3 values, blockDim.x == 256; result valid in thread 0
+template <int NV>
+__device__ __forceinline__ void block_sum(float (&v)[NV], float* smem /* >= 4*NV floats */) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = wave_sum(v[i]);
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) smem[wid * NV + i] = v[i];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int nw = blockDim.x >> 6;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            float s = 0.f;
+            for (int w = 0; w < nw; ++w) s += smem[w * NV + i];
+            v[i] = s;
+        }
+    }
+    __syncthreads();
+}

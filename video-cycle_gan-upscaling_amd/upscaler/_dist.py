@@ -1,0 +1,50 @@
+"""Data parallelism over frames: one process per GPU, torch.distributed (backend "nccl" == RCCL over
+xGMI on ROCm; "gloo" in the CPU tests).  The reference has no distributed code;
+this is the north_star's DP extension: replicas of G and D, one flat-bucket all-reduce per model per
+step (G <= 2.4 M, D <= 15.5 M fp32 elements), plus an all-reduce of the two D-output means so that
+non-linear GAN losses see the global batch."""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """Initialise the default process group from RANK / WORLD_SIZE / MASTER_* (torch.distributed.run)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world <= 1:
+        return None
+    if not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend=backend)
+    return dist.group.WORLD
+
+
+def allreduce_mean(flat, group):
+    """in-place mean over the ranks of one flat fp32 buffer (the model's whole gradient bucket)."""
+    if group is None:
+        return flat
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    flat.div_(dist.get_world_size(group))
+    return flat
+
+
+def broadcast_(flat, group, src=0):
+    if group is not None:
+        dist.broadcast(flat, src=src, group=group)
+    return flat
+
+
+def shard_batch(global_batch, group):
+    """per-rank slice [lo, hi) of a global batch of frames."""
+    if group is None:
+        return 0, global_batch
+    ws, rk = dist.get_world_size(group), dist.get_rank(group)
+    if global_batch % ws:
+        raise ValueError("global batch %d not divisible by world size %d" % (global_batch, ws))
+    per = global_batch // ws
+    return rk * per, (rk + 1) * per

@@ -1,0 +1,533 @@
+"""Device engine: parameter storage and layer forward/backward on top of the C ABI (include/vcg.h).
+
+torch is used only for device memory (torch.empty), the current HIP stream and host<->device
+copies; every arithmetic step is a libvcg_hip.so kernel.  Activations are fp32 NCHW.
+
+Layer <-> reference call sites (upscaling/upscaler/model.py):
+  Conv2D            :19,22,275,283,290,839-871     ConvT2D   :72
+  NormAct           :20-25,276,284-285,840-841     Dense     :876-884
+"""
+import ctypes
+import math
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from . import _lib as L
+
+BN_EPS = 1e-3          # keras BatchNormalization defaults
+BN_MOMENTUM = 0.99
+IN_EPS = 1e-5          # instance norm (canonical CycleGAN value; no reference counterpart)
+
+
+def same_pads(size, k, s):
+    """TF SAME: out = ceil(in/s); total = max((out-1)*s+k-in, 0); before = total//2."""
+    out = -(-size // s)
+    total = max((out - 1) * s + k - size, 0)
+    return out, total // 2, total - total // 2
+
+
+class Runtime:
+    """Per-process handle: library, device, grow-only workspace."""
+
+    _inst = None
+
+    def __init__(self):
+        self.lib = L.load()
+        self.device = L.require_gpu()
+        self._ws = None
+        self.prof = None      # optional kernel-timing hook set by bench.py
+
+    @classmethod
+    def get(cls):
+        if cls._inst is None:
+            cls._inst = Runtime()
+        return cls._inst
+
+    @property
+    def stream(self):
+        return torch.cuda.current_stream().cuda_stream
+
+    def workspace(self, nbytes):
+        nbytes = max(int(nbytes), 4096)
+        if self._ws is None or self._ws.numel() < nbytes:
+            self._ws = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8, device=self.device)
+        return self._ws.data_ptr(), self._ws.numel()
+
+    def empty(self, *shape):
+        return torch.empty(*shape, dtype=torch.float32, device=self.device)
+
+    def zeros(self, *shape):
+        t = self.empty(*shape)
+        L.check(self.lib.vcg_fill(t.data_ptr(), t.numel(), 0.0, self.stream), "vcg_fill")
+        return t
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+class Timed:
+    """Context manager used by bench.py to bracket launches of one kernel family with HIP events
+    on the stream the kernels run on."""
+
+    def __init__(self, rt, tag):
+        self.rt, self.tag = rt, tag
+
+    def __enter__(self):
+        p = self.rt.prof
+        if p is not None and self.tag in p.tags:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+        else:
+            self.e0 = None
+
+    def __exit__(self, *a):
+        if self.e0 is not None:
+            self.e1.record()
+            self.rt.prof.events.setdefault(self.tag, []).append((self.e0, self.e1))
+
+
+# =================================================================================================
+# parameter store: one flat fp32 buffer of trainables (+grads), one of non-trainable state
+# =================================================================================================
+class ParamStore:
+    def __init__(self):
+        self.specs = OrderedDict()   # name -> (shape, trainable, init)
+        self.params = None
+        self.state = None
+        self.grads = None
+        self.grads2 = None
+        self.views = {}
+        self.gviews = {}
+        self.g2views = {}
+
+    def declare(self, name, shape, trainable=True):
+        if name in self.specs:
+            raise ValueError("duplicate weight " + name)
+        self.specs[name] = (tuple(int(s) for s in shape), trainable)
+
+    def materialize(self, rt):
+        nt = sum(int(np.prod(s)) for s, t in self.specs.values() if t)
+        ns = sum(int(np.prod(s)) for s, t in self.specs.values() if not t)
+        self.params = rt.zeros(max(nt, 1))
+        self.grads = rt.zeros(max(nt, 1))
+        self.grads2 = rt.zeros(max(nt, 1))
+        self.state = rt.zeros(max(ns, 1))
+        ot = os_ = 0
+        self.offsets = {}
+        for name, (shape, trainable) in self.specs.items():
+            n = int(np.prod(shape))
+            if trainable:
+                self.views[name] = self.params[ot:ot + n].view(shape)
+                self.gviews[name] = self.grads[ot:ot + n].view(shape)
+                self.g2views[name] = self.grads2[ot:ot + n].view(shape)
+                self.offsets[name] = ot
+                ot += n
+            else:
+                self.views[name] = self.state[os_:os_ + n].view(shape)
+                os_ += n
+        self.n_trainable, self.n_state = nt, ns
+
+    def __getitem__(self, name):
+        return self.views[name]
+
+    def grad(self, name, which=0):
+        return (self.gviews if which == 0 else self.g2views)[name]
+
+    def count_params(self):
+        return sum(int(np.prod(s)) for s, _ in self.specs.values())
+
+    def set_weights(self, weights):
+        """weights: dict name -> array (Keras layouts).  Unknown / missing names raise."""
+        for name, arr in weights.items():
+            if name not in self.views:
+                raise KeyError("unknown weight " + name)
+            a = np.ascontiguousarray(np.asarray(arr, dtype=np.float32))
+            if tuple(a.shape) != self.specs[name][0]:
+                raise ValueError("shape mismatch for %s: %s vs %s" % (name, a.shape, self.specs[name][0]))
+            self.views[name].copy_(torch.from_numpy(a))
+        missing = [n for n in self.specs if n not in weights]
+        return missing
+
+    def get_weights(self):
+        return OrderedDict((n, self.views[n].detach().cpu().numpy().copy()) for n in self.specs)
+
+
+# =================================================================================================
+# initialisers (Keras defaults)
+# =================================================================================================
+def glorot_uniform(rng, shape, fan_in, fan_out):
+    limit = math.sqrt(6.0 / (fan_in + fan_out))
+    return rng.uniform(-limit, limit, size=shape).astype(np.float32)
+
+
+# =================================================================================================
+# layers
+# =================================================================================================
+class Layer:
+    def __init__(self, name):
+        self.name = name
+        self.rt = None
+        self.ps = None
+
+    def bind(self, rt, ps):
+        self.rt, self.ps = rt, ps
+
+    def init_weights(self, rng):
+        return {}
+
+    def refresh(self):
+        """called after the parameters changed (optimizer step / set_weights)"""
+
+
+class Conv2D(Layer):
+    """keras.layers.Conv2D(+fused bias/LeakyReLU/tanh epilogue).  padding: 'same' | 'valid' | int."""
+
+    def __init__(self, name, cin, cout, k, stride=1, padding="same", act=L.ACT_NONE, alpha=0.0):
+        super().__init__(name)
+        self.cin, self.cout, self.k, self.stride, self.padding = cin, cout, k, stride, padding
+        self.act, self.alpha = act, alpha
+        self.wt = None
+        self._wt_valid = False
+
+    def declare(self, ps):
+        ps.declare(self.name + "/kernel", (self.k, self.k, self.cin, self.cout))
+        ps.declare(self.name + "/bias", (self.cout,))
+
+    def init_weights(self, rng):
+        k = self.k
+        return {self.name + "/kernel": glorot_uniform(rng, (k, k, self.cin, self.cout), k * k * self.cin, k * k * self.cout),
+                self.name + "/bias": np.zeros((self.cout,), np.float32)}
+
+    def out_hw(self, h, w):
+        k, s = self.k, self.stride
+        if self.padding == "same":
+            oh, pt, _ = same_pads(h, k, s)
+            ow, pl, _ = same_pads(w, k, s)
+        elif self.padding == "valid":
+            oh, ow, pt, pl = (h - k) // s + 1, (w - k) // s + 1, 0, 0
+        else:
+            p = int(self.padding)
+            oh, ow, pt, pl = (h + 2 * p - k) // s + 1, (w + 2 * p - k) // s + 1, p, p
+        return oh, ow, pt, pl
+
+    def desc(self, n, h, w):
+        oh, ow, pt, pl = self.out_hw(h, w)
+        return L.ConvDesc(n, self.cin, h, w, self.cout, oh, ow, self.k, self.k, self.stride, pt, pl)
+
+    def refresh(self):
+        self._wt_valid = False
+
+    def _wt(self):
+        """per-tap transposed kernel (kh,kw,out,in), rebuilt lazily after each parameter change"""
+        rt = self.rt
+        if self.wt is None:
+            self.wt = rt.empty(self.k * self.k, self.cout, self.cin)
+        if not self._wt_valid:
+            L.check(rt.lib.vcg_kernel_transpose(self.ps[self.name + "/kernel"].data_ptr(), self.wt.data_ptr(),
+                                                self.k * self.k, self.cin, self.cout, rt.stream), "vcg_kernel_transpose")
+            self._wt_valid = True
+        return self.wt
+
+    def forward(self, x, residual=None, tag=None):
+        rt = self.rt
+        n, _, h, w = x.shape
+        d = self.desc(n, h, w)
+        y = rt.empty(n, self.cout, d.oh, d.ow)
+        ep = L.Epilogue(_ptr(self.ps[self.name + "/bias"]), self.act, float(self.alpha), None, _ptr(residual))
+        with Timed(rt, tag):
+            L.check(rt.lib.vcg_conv2d_fwd(ctypes.byref(d), x.data_ptr(), self.ps[self.name + "/kernel"].data_ptr(),
+                                          y.data_ptr(), ctypes.byref(ep), rt.stream), "vcg_conv2d_fwd[%s]" % self.name)
+        return y, (x, y if self.act != L.ACT_NONE else None, d)
+
+    def backward(self, ctx, dy, need_dx=True, param_grads=True, which=0, dx_residual=None, tag=None):
+        rt = self.rt
+        x, y, d = ctx
+        n = d.n
+        if self.act != L.ACT_NONE:
+            dz = rt.empty(*dy.shape)
+            L.check(rt.lib.vcg_act_bwd(y.data_ptr(), dy.data_ptr(), n, self.cout, d.oh * d.ow, self.act, float(self.alpha),
+                                       None, dz.data_ptr(), None, None, 0, rt.stream), "vcg_act_bwd[%s]" % self.name)
+            dy = dz
+        if param_grads:
+            need = rt.lib.vcg_conv2d_wgrad_workspace_bytes(ctypes.byref(d))
+            ws, wsn = rt.workspace(need)
+            with Timed(rt, tag and tag + "_wgrad"):
+                L.check(rt.lib.vcg_conv2d_wgrad(ctypes.byref(d), x.data_ptr(), dy.data_ptr(),
+                                                self.ps.grad(self.name + "/kernel", which).data_ptr(),
+                                                self.ps.grad(self.name + "/bias", which).data_ptr(), ws, wsn, rt.stream),
+                        "vcg_conv2d_wgrad[%s]" % self.name)
+        dx = None
+        if need_dx:
+            dx = rt.empty(n, self.cin, d.h, d.w)
+            with Timed(rt, tag and tag + "_dgrad"):
+                L.check(rt.lib.vcg_conv2d_dgrad(ctypes.byref(d), dy.data_ptr(), self.ps[self.name + "/kernel"].data_ptr(),
+                                                self._wt().data_ptr(), dx.data_ptr(), _ptr(dx_residual), rt.stream),
+                        "vcg_conv2d_dgrad[%s]" % self.name)
+        return dx
+
+
+class ConvT2D(Layer):
+    """keras.layers.Conv2DTranspose(strides=2, padding='same') + fused LeakyReLU (model.py:72-73)."""
+
+    def __init__(self, name, cin, cout, k, act=L.ACT_NONE, alpha=0.0):
+        super().__init__(name)
+        self.cin, self.cout, self.k, self.act, self.alpha = cin, cout, k, act, alpha
+        self.wt = None
+        self._wt_valid = False
+
+    def declare(self, ps):
+        ps.declare(self.name + "/kernel", (self.k, self.k, self.cout, self.cin))
+        ps.declare(self.name + "/bias", (self.cout,))
+
+    def init_weights(self, rng):
+        k = self.k
+        return {self.name + "/kernel": glorot_uniform(rng, (k, k, self.cout, self.cin), k * k * self.cout, k * k * self.cin),
+                self.name + "/bias": np.zeros((self.cout,), np.float32)}
+
+    def desc(self, n, h, w):
+        crop = max(self.k - 2, 0) // 2
+        return L.ConvDesc(n, self.cin, h, w, self.cout, 2 * h, 2 * w, self.k, self.k, 2, crop, crop)
+
+    def refresh(self):
+        self._wt_valid = False
+
+    def _wt(self):
+        rt = self.rt
+        if self.wt is None:
+            self.wt = rt.empty(self.k * self.k, self.cin, self.cout)
+        if not self._wt_valid:
+            L.check(rt.lib.vcg_kernel_transpose(self.ps[self.name + "/kernel"].data_ptr(), self.wt.data_ptr(),
+                                                self.k * self.k, self.cout, self.cin, rt.stream), "vcg_kernel_transpose")
+            self._wt_valid = True
+        return self.wt
+
+    def forward(self, x, tag=None):
+        rt = self.rt
+        n, _, h, w = x.shape
+        d = self.desc(n, h, w)
+        y = rt.empty(n, self.cout, d.oh, d.ow)
+        ep = L.Epilogue(_ptr(self.ps[self.name + "/bias"]), self.act, float(self.alpha), None, None)
+        with Timed(rt, tag):
+            L.check(rt.lib.vcg_conv_transpose2d_fwd(ctypes.byref(d), x.data_ptr(), self._wt().data_ptr(), y.data_ptr(),
+                                                    ctypes.byref(ep), rt.stream), "vcg_conv_transpose2d_fwd[%s]" % self.name)
+        return y, (x, y if self.act != L.ACT_NONE else None, d)
+
+    def backward(self, ctx, dy, need_dx=True, param_grads=True, which=0, tag=None):
+        rt = self.rt
+        x, y, d = ctx
+        if self.act != L.ACT_NONE:
+            dz = rt.empty(*dy.shape)
+            L.check(rt.lib.vcg_act_bwd(y.data_ptr(), dy.data_ptr(), d.n, self.cout, d.oh * d.ow, self.act, float(self.alpha),
+                                       None, dz.data_ptr(), None, None, 0, rt.stream), "vcg_act_bwd[%s]" % self.name)
+            dy = dz
+        if param_grads:
+            need = rt.lib.vcg_conv_transpose2d_wgrad_workspace_bytes(ctypes.byref(d))
+            ws, wsn = rt.workspace(need)
+            with Timed(rt, tag and tag + "_wgrad"):
+                L.check(rt.lib.vcg_conv_transpose2d_wgrad(ctypes.byref(d), x.data_ptr(), dy.data_ptr(),
+                                                          self.ps.grad(self.name + "/kernel", which).data_ptr(),
+                                                          self.ps.grad(self.name + "/bias", which).data_ptr(), ws, wsn,
+                                                          rt.stream), "vcg_conv_transpose2d_wgrad[%s]" % self.name)
+        dx = None
+        if need_dx:
+            dx = rt.empty(d.n, self.cin, d.h, d.w)
+            with Timed(rt, tag and tag + "_dgrad"):
+                L.check(rt.lib.vcg_conv_transpose2d_dgrad(ctypes.byref(d), dy.data_ptr(),
+                                                          self.ps[self.name + "/kernel"].data_ptr(), dx.data_ptr(), None,
+                                                          rt.stream), "vcg_conv_transpose2d_dgrad[%s]" % self.name)
+        return dx
+
+
+class NormAct(Layer):
+    """[BatchNormalization | instance norm | identity] -> [PReLU | LeakyReLU | none] -> [+ residual].
+
+    norm: 'batch' (Keras BN, gamma/beta/moving stats), 'instance' (non-affine), None.
+    act: ACT_NONE / ACT_LRELU / ACT_PRELU; PReLU owns a per-channel alpha named ``prelu_name``."""
+
+    def __init__(self, name, c, norm="batch", act=L.ACT_NONE, alpha=0.0, prelu_name=None):
+        super().__init__(name)
+        self.c, self.norm, self.act, self.alpha, self.prelu_name = c, norm, act, alpha, prelu_name
+
+    def declare(self, ps):
+        if self.norm == "batch":
+            ps.declare(self.name + "/gamma", (self.c,))
+            ps.declare(self.name + "/beta", (self.c,))
+            ps.declare(self.name + "/moving_mean", (self.c,), trainable=False)
+            ps.declare(self.name + "/moving_variance", (self.c,), trainable=False)
+        if self.act == L.ACT_PRELU:
+            ps.declare(self.prelu_name + "/alpha", (self.c,))
+
+    def init_weights(self, rng):
+        w = {}
+        if self.norm == "batch":
+            w[self.name + "/gamma"] = np.ones((self.c,), np.float32)
+            w[self.name + "/beta"] = np.zeros((self.c,), np.float32)
+            w[self.name + "/moving_mean"] = np.zeros((self.c,), np.float32)
+            w[self.name + "/moving_variance"] = np.ones((self.c,), np.float32)
+        if self.act == L.ACT_PRELU:
+            w[self.prelu_name + "/alpha"] = np.zeros((self.c,), np.float32)
+        return w
+
+    def _alpha_ptr(self):
+        return self.ps[self.prelu_name + "/alpha"].data_ptr() if self.act == L.ACT_PRELU else None
+
+    def forward(self, x, training, residual=None, update_moving=True):
+        rt, ps = self.rt, self.ps
+        lib = rt.lib
+        if x.dim() == 4:
+            n, c, h, w = x.shape
+            hw = h * w
+        else:
+            n, c = x.shape
+            hw = 1
+        y = rt.empty(*x.shape)
+        saved = None
+        if self.norm is None:
+            L.check(lib.vcg_norm_act_fwd(x.data_ptr(), n, c, hw, None, None, 0, self.act, float(self.alpha),
+                                         self._alpha_ptr(), _ptr(residual), y.data_ptr(), rt.stream), "vcg_norm_act_fwd")
+            return y, (x, None, None, (n, c, hw))
+        inst = self.norm == "instance"
+        rows = n if inst else 1
+        mode = L.NORM_INSTANCE if inst else L.NORM_BATCH
+        scale, shift, invstd = rt.empty(rows * c), rt.empty(rows * c), rt.empty(rows * c)
+        gamma = None if inst else ps[self.name + "/gamma"].data_ptr()
+        beta = None if inst else ps[self.name + "/beta"].data_ptr()
+        if training or inst:
+            mean, var = rt.empty(rows * c), rt.empty(rows * c)
+            ws, wsn = rt.workspace(lib.vcg_norm_stats_workspace_bytes(n, c, hw, mode))
+            L.check(lib.vcg_norm_stats(x.data_ptr(), n, c, hw, mode, mean.data_ptr(), var.data_ptr(), ws, wsn, rt.stream),
+                    "vcg_norm_stats[%s]" % self.name)
+            mm = mv = None
+            if not inst and update_moving:
+                mm, mv = ps[self.name + "/moving_mean"].data_ptr(), ps[self.name + "/moving_variance"].data_ptr()
+            # Keras' TF backend: fused path (4-D) reports the Bessel-corrected variance to the moving
+            # average, the 2-D path (Dense BN) the biased one
+            ub = (n * hw) if (x.dim() == 4 and not inst) else 0
+            L.check(lib.vcg_norm_finalize(mean.data_ptr(), var.data_ptr(), gamma, beta, c, rows,
+                                          IN_EPS if inst else BN_EPS, scale.data_ptr(), shift.data_ptr(), invstd.data_ptr(),
+                                          mm, mv, BN_MOMENTUM, ub, rt.stream), "vcg_norm_finalize")
+            saved = (mean, invstd)
+        else:
+            L.check(lib.vcg_norm_finalize(ps[self.name + "/moving_mean"].data_ptr(),
+                                          ps[self.name + "/moving_variance"].data_ptr(), gamma, beta, c, 1, BN_EPS,
+                                          scale.data_ptr(), shift.data_ptr(), invstd.data_ptr(), None, None, 0.0, 0,
+                                          rt.stream), "vcg_norm_finalize")
+        L.check(lib.vcg_norm_act_fwd(x.data_ptr(), n, c, hw, scale.data_ptr(), shift.data_ptr(), 1 if inst else 0, self.act,
+                                     float(self.alpha), self._alpha_ptr(), _ptr(residual), y.data_ptr(), rt.stream),
+                "vcg_norm_act_fwd[%s]" % self.name)
+        return y, (x, saved, mode, (n, c, hw))
+
+    def backward(self, ctx, dy, param_grads=True, which=0):
+        """returns dx; the residual branch's gradient is dy itself (caller handles it)."""
+        rt, ps = self.rt, self.ps
+        lib = rt.lib
+        x, saved, mode, (n, c, hw) = ctx
+        dx = rt.empty(*x.shape)
+        dalpha = ps.grad(self.prelu_name + "/alpha", which).data_ptr() if (self.act == L.ACT_PRELU and param_grads) else None
+        if self.norm is None:
+            ws, wsn = rt.workspace(lib.vcg_act_bwd_workspace_bytes(n, c, hw))
+            L.check(lib.vcg_act_bwd(x.data_ptr(), dy.data_ptr(), n, c, hw, self.act, float(self.alpha), self._alpha_ptr(),
+                                    dx.data_ptr(), dalpha, ws, wsn, rt.stream), "vcg_act_bwd[%s]" % self.name)
+            return dx
+        if saved is None:
+            raise RuntimeError("backward through inference-mode normalisation is not defined")
+        mean, invstd = saved
+        inst = self.norm == "instance"
+        gamma = None if inst else ps[self.name + "/gamma"].data_ptr()
+        beta = None if inst else ps[self.name + "/beta"].data_ptr()
+        dgamma = dbeta = None
+        if not inst and param_grads:
+            dgamma = ps.grad(self.name + "/gamma", which).data_ptr()
+            dbeta = ps.grad(self.name + "/beta", which).data_ptr()
+        ws, wsn = rt.workspace(lib.vcg_norm_act_bwd_workspace_bytes(n, c, hw, mode))
+        L.check(lib.vcg_norm_act_bwd(x.data_ptr(), dy.data_ptr(), n, c, hw, mode, mean.data_ptr(), invstd.data_ptr(), gamma,
+                                     beta, self.act, float(self.alpha), self._alpha_ptr(), 1, dx.data_ptr(), dgamma, dbeta,
+                                     dalpha, ws, wsn, rt.stream), "vcg_norm_act_bwd[%s]" % self.name)
+        return dx
+
+
+class Dense(Layer):
+    def __init__(self, name, cin, cout):
+        super().__init__(name)
+        self.cin, self.cout = cin, cout
+
+    def declare(self, ps):
+        ps.declare(self.name + "/kernel", (self.cin, self.cout))
+        ps.declare(self.name + "/bias", (self.cout,))
+
+    def init_weights(self, rng):
+        return {self.name + "/kernel": glorot_uniform(rng, (self.cin, self.cout), self.cin, self.cout),
+                self.name + "/bias": np.zeros((self.cout,), np.float32)}
+
+    def forward(self, x):
+        rt = self.rt
+        b = x.shape[0]
+        y = rt.empty(b, self.cout)
+        L.check(rt.lib.vcg_dense_fwd(x.data_ptr(), self.ps[self.name + "/kernel"].data_ptr(),
+                                     self.ps[self.name + "/bias"].data_ptr(), y.data_ptr(), b, self.cin, self.cout, rt.stream),
+                "vcg_dense_fwd[%s]" % self.name)
+        return y, (x,)
+
+    def backward(self, ctx, dy, need_dx=True, param_grads=True, which=0):
+        rt = self.rt
+        (x,) = ctx
+        b = x.shape[0]
+        if param_grads:
+            L.check(rt.lib.vcg_dense_wgrad(x.data_ptr(), dy.data_ptr(), self.ps.grad(self.name + "/kernel", which).data_ptr(),
+                                           self.ps.grad(self.name + "/bias", which).data_ptr(), b, self.cin, self.cout,
+                                           rt.stream), "vcg_dense_wgrad[%s]" % self.name)
+        dx = None
+        if need_dx:
+            dx = rt.empty(b, self.cin)
+            L.check(rt.lib.vcg_dense_dgrad(dy.data_ptr(), self.ps[self.name + "/kernel"].data_ptr(), dx.data_ptr(), b, self.cin,
+                                           self.cout, rt.stream), "vcg_dense_dgrad[%s]" % self.name)
+        return dx
+
+
+# =================================================================================================
+# layout helpers at the API edge
+# =================================================================================================
+def to_device_nchw(rt, x):
+    """numpy / torch NHWC float array -> device fp32 NCHW (vcg_nhwc_to_nchw)."""
+    if isinstance(x, torch.Tensor):
+        t = x.to(device=rt.device, dtype=torch.float32).contiguous()
+    else:
+        a = np.ascontiguousarray(np.asarray(x, dtype=np.float32))
+        t = torch.from_numpy(a).to(rt.device)
+    if t.dim() != 4:
+        raise ValueError("expected a 4-D NHWC batch, got shape %s" % (tuple(t.shape),))
+    n, h, w, c = t.shape
+    out = rt.empty(n, c, h, w)
+    L.check(rt.lib.vcg_nhwc_to_nchw(t.data_ptr(), out.data_ptr(), n, h, w, c, rt.stream), "vcg_nhwc_to_nchw")
+    return out
+
+
+def to_nhwc(rt, t):
+    """device NCHW -> device NHWC (vcg_nchw_to_nhwc)."""
+    n, c, h, w = t.shape
+    out = rt.empty(n, h, w, c)
+    L.check(rt.lib.vcg_nchw_to_nhwc(t.data_ptr(), out.data_ptr(), n, h, w, c, rt.stream), "vcg_nchw_to_nhwc")
+    return out
+
+
+def mean_scalar(rt, t):
+    """device scalar tensor holding mean(t) (vcg_mean_reduce)."""
+    out = rt.empty(1)
+    ws, wsn = rt.workspace(rt.lib.vcg_mean_reduce_workspace_bytes(t.numel()))
+    L.check(rt.lib.vcg_mean_reduce(t.data_ptr(), t.numel(), out.data_ptr(), ws, wsn, rt.stream), "vcg_mean_reduce")
+    return out
+
+
+def filled_like(rt, t, value):
+    out = rt.empty(*t.shape)
+    L.check(rt.lib.vcg_fill(out.data_ptr(), out.numel(), float(value), rt.stream), "vcg_fill")
+    return out
+
+
+def axpby(rt, x, y, a, b):
+    """y = a*x + b*y"""
+    L.check(rt.lib.vcg_axpby(x.data_ptr(), y.data_ptr(), y.numel(), float(a), float(b), rt.stream), "vcg_axpby")

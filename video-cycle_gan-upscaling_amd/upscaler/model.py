@@ -1,0 +1,769 @@
+"""MI355X-native mirror of the reference's ``upscaler.model`` module for the GAN hot path.
+
+Same names, signatures and call protocol as upscaling/upscaler/model.py (reference) for
+  make_upscaler_orig (:267), make_discriminator_simple_512 (:836), make_discriminator_thin_512 (:901),
+  wasserstein_loss (:159), GanLosses/WassersteinLosses/RelativisticLosses (:166-261),
+  make_and_compile_gan (:1017), make_and_compile_gan2 (:1057), compile_training_model (:1130), Adam,
+and the Keras ``Model`` methods its callers use: predict / train_on_batch / save / trainable /
+input_shape / output_shape / name (train_gan3.py:346-368).  Arrays cross this API as NHWC (numpy or
+torch), exactly as in the reference; on the device everything is fp32 NCHW and every arithmetic step
+is a hand-written gfx950 kernel from libvcg_hip.so (include/vcg.h).  There is no CPU fallback.
+
+Extensions named by north_star with no reference counterpart:
+  make_discriminator_patchgan_70, ``norm='instance'``.
+"""
+import math
+from abc import ABCMeta, abstractmethod
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from . import _engine as E
+from . import _lib as L
+
+
+# =================================================================================================
+# optimizer + losses (host-side objects; the arithmetic runs in vcg_adam_keras_multi / vcg_mean_reduce)
+# =================================================================================================
+class Adam:
+    """keras.optimizers.Adam defaults (lr 1e-3, beta 0.9/0.999, epsilon 1e-7, no decay).  One instance
+    shared by several compiled models shares ``iterations`` like Keras does (model.py:1026,1066)."""
+
+    def __init__(self, lr=0.001, beta_1=0.9, beta_2=0.999, epsilon=1e-7, decay=0.0, amsgrad=False):
+        if decay != 0.0 or amsgrad:
+            raise NotImplementedError("Adam(decay/amsgrad) is outside the hot path")
+        self.lr, self.beta_1, self.beta_2, self.epsilon = lr, beta_1, beta_2, epsilon
+        self.iterations = 0
+
+    def lr_t(self):
+        t = self.iterations + 1
+        return self.lr * math.sqrt(1.0 - self.beta_2 ** t) / (1.0 - self.beta_1 ** t)
+
+
+_DEFAULT_ADAM = Adam()     # mirrors the reference's default-argument instance
+
+
+def wasserstein_loss(y_true, y_pred):
+    """K.mean(y_true * y_pred) (model.py:159-160) evaluated on host arrays."""
+    return float(np.mean(np.asarray(y_true, np.float64).reshape(-1, 1) * np.asarray(y_pred, np.float64).reshape(len(y_pred), -1)))
+
+
+def mean_squared_error(y_true, y_pred):
+    return float(np.mean((np.asarray(y_pred, np.float64) - np.asarray(y_true, np.float64)) ** 2))
+
+
+def mean_absolute_error(y_true, y_pred):
+    return float(np.mean(np.abs(np.asarray(y_pred, np.float64) - np.asarray(y_true, np.float64))))
+
+
+class PixelLoss:
+    """Pixel content loss = the non-VGG term of VGG_MSE_LOSS / VGG_MAE_LOSS (model.py:137,157); the VGG19
+    perceptual term needs downloaded ImageNet weights and is out of scope."""
+
+    def __init__(self, kind="mse"):
+        if kind not in ("mse", "mae"):
+            raise ValueError(kind)
+        self.kind = kind
+
+    def loss(self, y_true, y_pred):
+        return mean_squared_error(y_true, y_pred) if self.kind == "mse" else mean_absolute_error(y_true, y_pred)
+
+
+def _content_kind(content_loss):
+    if isinstance(content_loss, str):
+        k = {"mse": "mse", "mean_squared_error": "mse", "mae": "mae", "mean_absolute_error": "mae"}.get(content_loss)
+        if k is None:
+            raise ValueError("unsupported content loss %r" % (content_loss,))
+        return k
+    if content_loss is mean_squared_error:
+        return "mse"
+    if content_loss is mean_absolute_error:
+        return "mae"
+    owner = getattr(content_loss, "__self__", None)
+    if isinstance(owner, PixelLoss):
+        return owner.kind
+    if isinstance(content_loss, PixelLoss):
+        return content_loss.kind
+    raise NotImplementedError(
+        "content loss %r is not on the MI355X hot path: use 'mse'/'mae' or PixelLoss(kind).loss "
+        "(the VGG19 perceptual losses need ImageNet weights, SURVEY.md section 8f)" % (content_loss,))
+
+
+def _act_value_and_grad(name, x):
+    """loss_activation(x) and its derivative for a python float x (model.py:172-181)."""
+    if name == "sigmoid":
+        s = 1.0 / (1.0 + math.exp(-x))
+        return s, s * (1 - s)
+    if name == "log-sigm":
+        # log(sigmoid(x)) ; derivative 1 - sigmoid(x)
+        s = 1.0 / (1.0 + math.exp(-x)) if x > -700 else 0.0
+        val = -math.log1p(math.exp(-x)) if x > -30 else x
+        return val, 1.0 - s
+    if name == "tanh":
+        t = math.tanh(x)
+        return t, 1 - t * t
+    if name == "bi-log":
+        a = abs(x)
+        sgn = 1.0 if x >= 0 else -1.0
+        u, v = x / (1 + a), math.log(a + 2)
+        du = 1.0 / (1 + a) ** 2
+        dv = sgn / (a + 2)
+        return u * v, du * v + u * dv
+    return x, 1.0
+
+
+class GanLosses(metaclass=ABCMeta):
+    """model.py:166-210.  ``real_output`` / ``fake_output`` hold discriminator outputs (host arrays when
+    the closures are evaluated by hand; the training models read them on the device)."""
+
+    def __init__(self, loss_activation="log-sigm", real_output=None, fake_output=None):
+        self._real_output = real_output
+        self._fake_output = fake_output
+        self.loss_activation_name = loss_activation if loss_activation in ("sigmoid", "log-sigm", "tanh", "bi-log") else "none"
+        self.loss_activation = lambda x: _act_value_and_grad(self.loss_activation_name, float(x))[0]
+
+    @property
+    def real_output(self):
+        return self._real_output
+
+    @real_output.setter
+    def real_output(self, real_output):
+        self._real_output = real_output
+
+    @property
+    def fake_output(self):
+        return self._fake_output
+
+    @fake_output.setter
+    def fake_output(self, fake_output):
+        self._fake_output = fake_output
+
+    @property
+    @abstractmethod
+    def discriminator_loss(self):
+        pass
+
+    @property
+    @abstractmethod
+    def generator_loss(self):
+        pass
+
+    # what the device trainer needs to know
+    relativistic = False
+
+
+class WassersteinLosses(GanLosses):
+    """model.py:215-235"""
+
+    @property
+    def discriminator_loss(self):
+        def loss(y_true, y_pred):
+            return float(np.mean(self._real_output) - np.mean(self._fake_output))
+        return loss
+
+    @property
+    def generator_loss(self):
+        def loss(y_true, y_pred):
+            return float(np.mean(self._fake_output))
+        return loss
+
+
+class RelativisticLosses(GanLosses):
+    """model.py:239-261"""
+    relativistic = True
+
+    @property
+    def discriminator_loss(self):
+        def loss(y_true, y_pred):
+            return self.loss_activation(np.mean(self._real_output) - np.mean(self._fake_output))
+        return loss
+
+    @property
+    def generator_loss(self):
+        def loss(y_true, y_pred):
+            return self.loss_activation(np.mean(self._fake_output) - np.mean(self._real_output))
+        return loss
+
+
+# =================================================================================================
+# networks
+# =================================================================================================
+class Model:
+    """Device-resident network with the Keras ``Model`` surface the reference's callers use."""
+
+    def __init__(self, name, input_shape, seed):
+        self.name = name
+        self.trainable = True
+        self._in_shape = tuple(input_shape)
+        self.rt = E.Runtime.get()
+        self.ps = E.ParamStore()
+        self.layers = []
+        self._seed = seed
+
+    # -- construction helpers ---------------------------------------------------------------------
+    def _add(self, layer):
+        layer.declare(self.ps)
+        self.layers.append(layer)
+        return layer
+
+    def _finish(self):
+        self.ps.materialize(self.rt)
+        rng = np.random.RandomState(self._seed)
+        w = {}
+        for l in self.layers:
+            l.bind(self.rt, self.ps)
+            w.update(l.init_weights(rng))
+        self.ps.set_weights(w)
+
+    # -- Keras surface ------------------------------------------------------------------------------
+    @property
+    def input_shape(self):
+        return (None,) + self._in_shape
+
+    @property
+    def output_shape(self):
+        return (None,) + tuple(self._out_shape(self._in_shape))
+
+    def count_params(self):
+        return self.ps.count_params()
+
+    def get_weights_dict(self):
+        return self.ps.get_weights()
+
+    def set_weights_dict(self, weights):
+        missing = self.ps.set_weights(weights)
+        if missing:
+            raise KeyError("missing weights: %s" % missing[:5])
+        self.refresh()
+
+    # the dict uses the reference's layer/weight names and Keras layouts, so a reference checkpoint
+    # converted to {name: array} loads unchanged
+    from_reference_weights = set_weights_dict
+
+    def refresh(self):
+        for l in self.layers:
+            l.refresh()
+
+    def save(self, path):
+        """Model.save(path) (train_gan3.py:367-368): flat archive keyed by the reference's layer names."""
+        from safetensors.numpy import save_file
+        save_file({k: v for k, v in self.ps.get_weights().items()}, path,
+                  metadata={"format": "vcg-amd", "name": str(self.name), "input_shape": repr(self._in_shape)})
+
+    def load_weights(self, path):
+        from safetensors.numpy import load_file
+        self.set_weights_dict(load_file(path))
+
+    def predict(self, x, batch_size=32):
+        """learning phase 0 (BN uses moving statistics); NHWC in -> NHWC out, same container type."""
+        rt = self.rt
+        is_torch = isinstance(x, torch.Tensor)
+        n = x.shape[0]
+        outs = []
+        for i in range(0, n, batch_size):
+            xb = E.to_device_nchw(rt, x[i:i + batch_size])
+            y, _ = self.forward(xb, training=False)
+            outs.append(self._export(y))
+        out = outs[0] if len(outs) == 1 else torch.cat(outs, 0)
+        return out if is_torch else out.cpu().numpy()
+
+    def _export(self, y):
+        return E.to_nhwc(self.rt, y) if y.dim() == 4 else y
+
+    def __call__(self, x):
+        return self.predict(x)
+
+
+class UpscalerOrig(Model):
+    """make_upscaler_orig topology (model.py:267-295)."""
+
+    def __init__(self, output_image_shape, kernel_size, filters, upscale_factor, res_block_num, norm, seed):
+        f = upscale_factor
+        super().__init__("upscaler_orig", (output_image_shape[0] // f, output_image_shape[1] // f, output_image_shape[2]), seed)
+        self.upscale_times = int(math.log(f, 2))
+        self.factor = 2 ** self.upscale_times
+        k = kernel_size
+        nrm = {"batch": "batch", "instance": "instance"}[norm]
+        self.c_init = self._add(E.Conv2D("initial/conv", output_image_shape[2], filters, 9))
+        self.a_init = self._add(E.NormAct("initial/prelu_op", filters, None, L.ACT_PRELU, prelu_name="initial/prelu"))
+        self.blocks = []
+        for i in range(res_block_num):
+            n = "res_block/%d" % i
+            self.blocks.append((
+                self._add(E.Conv2D(n + "/conv_pre", filters, filters, k)),
+                self._add(E.NormAct(n + "/batch_norm_pre", filters, nrm, L.ACT_PRELU, prelu_name=n + "/prelu")),
+                self._add(E.Conv2D(n + "/conv_post", filters, filters, k)),
+                self._add(E.NormAct(n + "/batch_norm_post", filters, nrm)),
+            ))
+        self.c_pre = self._add(E.Conv2D("prefinal/conv2d", filters, 64, k))          # 64: model.py:283
+        self.n_pre = self._add(E.NormAct("prefinal/batch_norm", 64, nrm))
+        self.ups = []
+        cin = 64
+        for i in range(self.upscale_times):
+            self.ups.append(self._add(E.ConvT2D("upscaling/%d/block/conv_transp" % i, cin, 256, k, L.ACT_LRELU, 0.2)))
+            cin = 256                                                                 # 256: model.py:288
+        self.c_fin = self._add(E.Conv2D("final/conv", cin, 3, 9, act=L.ACT_TANH))
+        self._finish()
+
+    def _out_shape(self, s):
+        return (s[0] * self.factor, s[1] * self.factor, 3)
+
+    def forward(self, x, training):
+        tape = []
+        h, c = self.c_init.forward(x); tape.append(c)
+        h, c = self.a_init.forward(h, training); tape.append(c)
+        skip = h
+        for (c1, n1, c2, n2) in self.blocks:
+            gen = h
+            h, a = c1.forward(h, tag="trunk_conv"); tape.append(a)
+            h, a = n1.forward(h, training); tape.append(a)
+            h, a = c2.forward(h, tag="trunk_conv"); tape.append(a)
+            h, a = n2.forward(h, training, residual=gen); tape.append(a)
+        h, a = self.c_pre.forward(h, tag="trunk_conv"); tape.append(a)
+        h, a = self.n_pre.forward(h, training, residual=skip); tape.append(a)
+        for u in self.ups:
+            h, a = u.forward(h, tag="convt"); tape.append(a)
+        h, a = self.c_fin.forward(h, tag="final_conv"); tape.append(a)
+        return h, tape
+
+    def backward(self, tape, dy, which=0):
+        """gradient of all trainables into grads[which]; dy = dL/d(output) NCHW."""
+        rt = self.rt
+        tape = list(tape)
+        d = self.c_fin.backward(tape.pop(), dy, True, True, which, tag="final_conv")
+        for u in reversed(self.ups):
+            d = u.backward(tape.pop(), d, True, True, which, tag="convt")
+        # s = skip + BN(conv(h)):  d flows to both
+        dskip = d
+        d = self.n_pre.backward(tape.pop(), d, True, which)
+        d = self.c_pre.backward(tape.pop(), d, True, True, which, tag="trunk_conv")
+        for (c1, n1, c2, n2) in reversed(self.blocks):
+            dres = d                                  # gradient wrt the block output = wrt `gen` branch too
+            d = n2.backward(tape.pop(), d, True, which)
+            d = c2.backward(tape.pop(), d, True, True, which, tag="trunk_conv")
+            d = n1.backward(tape.pop(), d, True, which)
+            d = c1.backward(tape.pop(), d, True, True, which, dx_residual=dres, tag="trunk_conv")
+        # d is now dL/d(a_init output) from the trunk; add the long-skip gradient
+        E.axpby(rt, dskip, d, 1.0, 1.0)
+        d = self.a_init.backward(tape.pop(), d, True, which)
+        self.c_init.backward(tape.pop(), d, False, True, which)
+        return None
+
+
+class DiscriminatorStack(Model):
+    """Strided-conv critic with Flatten/Dense head: make_discriminator_simple_512 (model.py:836-896) and
+    make_discriminator_thin_512 (:901-961)."""
+
+    def __init__(self, input_shape, filters, activation, seed, name):
+        super().__init__(name, input_shape, seed)
+        self.activation = activation
+        self.convs = []
+        cin = input_shape[2]
+        h, w = input_shape[0], input_shape[1]
+        for i, f in enumerate(filters):
+            n = "discriminator/block_%d" % (i + 1)
+            s = 1 if i == 0 else 2
+            self.convs.append((self._add(E.Conv2D(n + "/Conv2d", cin, f, 3, s)),
+                               self._add(E.NormAct(n + "/BatchNorm", f, "batch", L.ACT_LRELU, 0.1))))
+            if s == 2:
+                h, w = -(-h // 2), -(-w // 2)
+            cin = f
+        self.flat = (h, w, cin)
+        self.d1 = self._add(E.Dense("discriminator/final/Dense_1", h * w * cin, 1024))
+        self.b1 = self._add(E.NormAct("discriminator/final/BatchNorm_1", 1024, "batch", L.ACT_LRELU, 0.1))
+        self.d2 = self._add(E.Dense("discriminator/final/Dense_2", 1024, 32))
+        self.b2 = self._add(E.NormAct("discriminator/final/BatchNorm_2", 32, "batch", L.ACT_LRELU, 0.1))
+        self.d3 = self._add(E.Dense("discriminator/final/Dense_3", 32, 1))
+        self._finish()
+
+    def _out_shape(self, s):
+        return (1,)
+
+    @property
+    def output_shape(self):
+        return (None, 1)
+
+    def forward(self, x, training, update_moving=True):
+        if tuple(x.shape[2:]) != tuple(self._in_shape[:2]):
+            raise ValueError("discriminator built for %s, got %s" % (self._in_shape[:2], tuple(x.shape[2:])))
+        tape = []
+        h = x
+        for i, (cv, na) in enumerate(self.convs):
+            h, a = cv.forward(h, tag="d_conv"); tape.append(a)
+            h, a = na.forward(h, training, update_moving=update_moving); tape.append(a)
+        hf = E.to_nhwc(self.rt, h)                     # Flatten of NHWC is (h,w,c)-major (Appendix A)
+        tape.append(tuple(h.shape))
+        h = hf.view(hf.shape[0], -1)
+        for dn, bn in ((self.d1, self.b1), (self.d2, self.b2)):
+            h, a = dn.forward(h); tape.append(a)
+            h, a = bn.forward(h, training, update_moving=update_moving); tape.append(a)
+        h, a = self.d3.forward(h); tape.append(a)
+        if self.activation not in (None, "none"):
+            raise NotImplementedError("discriminator output activation %r: train with activation='none' "
+                                      "(the reference's default, model.py:836)" % (self.activation,))
+        return h, tape
+
+    def backward(self, tape, dy, need_dx=False, param_grads=True, which=0):
+        rt = self.rt
+        tape = list(tape)
+        d = self.d3.backward(tape.pop(), dy, True, param_grads, which)
+        for dn, bn in ((self.d2, self.b2), (self.d1, self.b1)):
+            d = bn.backward(tape.pop(), d, param_grads, which)
+            d = dn.backward(tape.pop(), d, True, param_grads, which)
+        n, c, h, w = tape.pop()
+        dn_ = rt.empty(n, c, h, w)
+        L.check(rt.lib.vcg_nhwc_to_nchw(d.data_ptr(), dn_.data_ptr(), n, h, w, c, rt.stream), "vcg_nhwc_to_nchw")
+        d = dn_
+        for i, (cv, na) in reversed(list(enumerate(self.convs))):
+            d = na.backward(tape.pop(), d, param_grads, which)
+            d = cv.backward(tape.pop(), d, need_dx or i > 0, param_grads, which, tag="d_conv")
+        return d
+
+
+class DiscriminatorPatchGAN(Model):
+    """70x70 PatchGAN (north_star extension): C64-C128-C256 (k4 s2),
+    C512 (k4 s1), C1 (k4 s1), zero padding 1, LeakyReLU 0.2, instance (default) or batch norm on the
+    three middle blocks."""
+    SPEC = ((64, 2, False), (128, 2, True), (256, 2, True), (512, 1, True), (1, 1, False))
+
+    def __init__(self, input_shape, activation, norm, seed):
+        super().__init__("discriminator_patchgan_70", input_shape, seed)
+        self.activation = activation
+        self.convs = []
+        cin = input_shape[2]
+        for i, (f, s, has_norm) in enumerate(self.SPEC):
+            n = "discriminator/block_%d" % (i + 1)
+            last = i == len(self.SPEC) - 1
+            if has_norm:
+                cv = self._add(E.Conv2D(n + "/Conv2d", cin, f, 4, s, 1))
+                na = self._add(E.NormAct(n + "/BatchNorm", f, norm, L.ACT_LRELU, 0.2))
+            else:
+                cv = self._add(E.Conv2D(n + "/Conv2d", cin, f, 4, s, 1, L.ACT_NONE if last else L.ACT_LRELU, 0.2))
+                na = None
+            self.convs.append((cv, na))
+            cin = f
+        self._finish()
+
+    def _out_shape(self, s):
+        h, w = s[0], s[1]
+        for cv, _ in self.convs:
+            h, w, _, _ = cv.out_hw(h, w)
+        return (h, w, 1)
+
+    def forward(self, x, training, update_moving=True):
+        tape = []
+        h = x
+        for cv, na in self.convs:
+            h, a = cv.forward(h, tag="d_conv"); tape.append(a)
+            if na is not None:
+                h, a = na.forward(h, training, update_moving=update_moving); tape.append(a)
+        if self.activation not in (None, "none"):
+            raise NotImplementedError("discriminator output activation %r" % (self.activation,))
+        return h, tape
+
+    def backward(self, tape, dy, need_dx=False, param_grads=True, which=0):
+        tape = list(tape)
+        d = dy
+        for i, (cv, na) in reversed(list(enumerate(self.convs))):
+            if na is not None:
+                d = na.backward(tape.pop(), d, param_grads, which)
+            d = cv.backward(tape.pop(), d, need_dx or i > 0, param_grads, which, tag="d_conv")
+        return d
+
+
+# =================================================================================================
+# factories -- reference signatures
+# =================================================================================================
+def make_upscaler_orig(output_image_shape, kernel_size=5, filters=64, upscale_factor=4, res_block_num=16,
+                       norm="batch", seed=7):
+    """model.py:267-295.  ``norm='instance'`` and ``seed`` are extensions (keyword-only in spirit)."""
+    if upscale_factor < 1 or (upscale_factor & (upscale_factor - 1)) != 0:
+        raise ValueError("upscale_factor must be a power of two (train_gan3.py:120-122)")
+    return UpscalerOrig(tuple(output_image_shape), kernel_size, filters, upscale_factor, res_block_num, norm, seed)
+
+
+def make_discriminator_simple_512(input_shape, activation="none", seed=11):
+    """model.py:836-896"""
+    return DiscriminatorStack(tuple(input_shape), (64, 128, 256, 512, 512, 512, 512, 512, 512), activation, seed,
+                              "discriminator_simple_512")
+
+
+def make_discriminator_thin_512(input_shape, activation="none", seed=11):
+    """model.py:901-961"""
+    return DiscriminatorStack(tuple(input_shape), (64,) + (128,) * 8, activation, seed, "discriminator_thin_512")
+
+
+def make_discriminator_patchgan_70(input_shape, activation="none", norm="instance", seed=11):
+    """north_star extension following the reference's factory naming pattern."""
+    return DiscriminatorPatchGAN(tuple(input_shape), activation, norm, seed)
+
+
+# =================================================================================================
+# training wiring -- make_and_compile_gan / make_and_compile_gan2 / compile_training_model
+# =================================================================================================
+class _Slots:
+    """Adam m/v for one compiled model (Keras creates separate slots per get_updates call)."""
+
+    def __init__(self, model):
+        rt = model.rt
+        self.m = rt.zeros(max(model.ps.n_trainable, 1))
+        self.v = rt.zeros(max(model.ps.n_trainable, 1))
+
+
+class GanTrainer:
+    """Shared state behind the three training models: who updates what, with which loss."""
+
+    def __init__(self, generator, discriminator, wiring, content_kind, content_w, losses, disc_w, optimizer,
+                 process_group=None):
+        self.G, self.D = generator, discriminator
+        self.rt = generator.rt
+        self.wiring = wiring
+        self.content_kind, self.cw, self.dw = content_kind, float(content_w), float(disc_w)
+        self.losses = losses            # GanLosses instance (gan2) or None (v1: wasserstein_loss)
+        self.opt = optimizer
+        self.g_slots, self.d_slots = _Slots(generator), _Slots(discriminator)
+        self.pg = process_group
+
+    # -- pieces ---------------------------------------------------------------------------------------
+    def _adam(self, model, slots, which=0):
+        rt = self.rt
+        ps = model.ps
+        g = ps.grads if which == 0 else ps.grads2
+        if self.pg is not None:
+            from . import _dist
+            _dist.allreduce_mean(g, self.pg)
+        L.check(rt.lib.vcg_adam_keras_multi(ps.params.data_ptr(), g.data_ptr(), slots.m.data_ptr(), slots.v.data_ptr(),
+                                            ps.n_trainable, float(self.opt.lr_t()), float(self.opt.beta_1),
+                                            float(self.opt.beta_2), float(self.opt.epsilon), rt.stream),
+                "vcg_adam_keras_multi")
+        self.opt.iterations += 1
+        model.refresh()
+
+    def _global_mean(self, t):
+        m = E.mean_scalar(self.rt, t)
+        if self.pg is not None:
+            from . import _dist
+            _dist.allreduce_mean(m, self.pg)
+        return m
+
+    # -- the three reference calls ----------------------------------------------------------------------
+    def predict(self, lr_nchw):
+        y, _ = self.G.forward(lr_nchw, training=False)
+        return y
+
+    def disc_step(self, hr, fake):
+        """disc_train.train_on_batch (train_gan3.py:353 / train_gan.py:315).  hr, fake: device NCHW."""
+        rt, D = self.rt, self.D
+        if self.wiring == "gan2":
+            out_r, tape_r = D.forward(hr, True, True)
+            out_f, tape_f = D.forward(fake, True, True)
+            mr, mf = self._global_mean(out_r), self._global_mean(out_f)
+            if self.losses.relativistic:
+                delta = float(mr.item()) - float(mf.item())
+                val, g = _act_value_and_grad(self.losses.loss_activation_name, delta)
+                loss = val
+            else:
+                g, loss = 1.0, None
+            D.backward(tape_r, E.filled_like(rt, out_r, g / out_r.numel()), False, True, 0)
+            D.backward(tape_f, E.filled_like(rt, out_f, -g / out_f.numel()), False, True, 1)
+            E.axpby(rt, D.ps.grads2, D.ps.grads, 1.0, 1.0)
+            if loss is None:
+                loss = (mr, mf)
+        else:
+            x = torch.cat([hr, fake], 0)       # device-side concatenation of the two batches (memory op)
+            out, tape = D.forward(x, True, True)
+            nb = hr.shape[0]
+            per = out.numel() // out.shape[0]
+            dy = rt.empty(*out.shape)
+            tot = out.numel()
+            L.check(rt.lib.vcg_fill(dy.data_ptr(), nb * per, 1.0 / tot, rt.stream), "vcg_fill")
+            L.check(rt.lib.vcg_fill(dy.data_ptr() + 4 * nb * per, tot - nb * per, -1.0 / tot, rt.stream), "vcg_fill")
+            D.backward(tape, dy, False, True, 0)
+            mr = E.mean_scalar(rt, out[:nb])
+            mf = E.mean_scalar(rt, out[nb:])
+            loss = (mr, mf, nb * per / tot, (tot - nb * per) / tot)
+        self._adam(D, self.d_slots)
+        return loss
+
+    def gan_step(self, lr, hr):
+        """gan_train.train_on_batch (train_gan3.py:354 / train_gan.py:317)."""
+        rt, G, D = self.rt, self.G, self.D
+        fake, gtape = G.forward(lr, True)
+        out_f, dtape = D.forward(fake, True, False)          # frozen D: batch stats, no moving update
+        content = rt.empty(1)
+        dfake = rt.empty(*fake.shape)
+        ws, wsn = rt.workspace(rt.lib.vcg_mean_reduce_workspace_bytes(fake.numel()))
+        L.check(rt.lib.vcg_pixel_loss(fake.data_ptr(), hr.data_ptr(), fake.numel(),
+                                      L.LOSS_MSE if self.content_kind == "mse" else L.LOSS_MAE, self.cw, content.data_ptr(),
+                                      dfake.data_ptr(), ws, wsn, rt.stream), "vcg_pixel_loss")
+        mf = self._global_mean(out_f)
+        adv = mf
+        g = 1.0
+        if self.wiring == "gan2" and self.losses.relativistic:
+            out_r, _ = D.forward(hr, True, False)
+            mr = self._global_mean(out_r)
+            delta = float(mf.item()) - float(mr.item())
+            adv, g = _act_value_and_grad(self.losses.loss_activation_name, delta)
+        d_adv = D.backward(dtape, E.filled_like(rt, out_f, self.dw * g / out_f.numel()), True, False, 0)
+        E.axpby(rt, d_adv, dfake, 1.0, 1.0)
+        G.backward(gtape, dfake, 0)
+        self._adam(G, self.g_slots)
+        return content, adv
+
+    # -- loss read-back ---------------------------------------------------------------------------------
+    def disc_loss_value(self, loss):
+        if isinstance(loss, tuple):
+            if len(loss) == 2:
+                return float(loss[0].item()) - float(loss[1].item())
+            mr, mf, wr, wf = loss
+            return float(mr.item()) * wr - float(mf.item()) * wf
+        return float(loss)
+
+    def gan_loss_values(self, content, adv):
+        c = float(content.item())
+        a = float(adv.item()) if isinstance(adv, torch.Tensor) else float(adv)
+        return [self.cw * c + self.dw * a, c, a]
+
+    def train_step(self, lr, hr):
+        """One loop-body iteration (train_gan3.py:346-354) without host round trips between the three
+        calls; lr/hr are device NCHW tensors.  Returns (loss_disc, loss_gan, loss_gan_gen, loss_gan_disc)."""
+        fake = self.predict(lr)
+        ld = self.disc_step(hr, fake)
+        content, adv = self.gan_step(lr, hr)
+        ld = self.disc_loss_value(ld)
+        lg = self.gan_loss_values(content, adv)
+        return ld, lg[0], lg[1], lg[2]
+
+
+class TrainingModel:
+    """One of the three compiled models returned by make_and_compile_gan[2]."""
+
+    def __init__(self, trainer, kind, name):
+        self.trainer, self.kind, self.name = trainer, kind, name
+        self.rt = trainer.rt
+
+    def predict(self, x, batch_size=32):
+        t = self.trainer
+        if self.kind == "gen":
+            return t.G.predict(x, batch_size)
+        if self.kind == "disc":
+            xs = x if isinstance(x, (list, tuple)) else [x]
+            return t.D.predict(xs[-1], batch_size)
+        xs = x if isinstance(x, (list, tuple)) else [x]
+        g = t.G.predict(xs[0], batch_size)
+        return [g, t.D.predict(g, batch_size)]
+
+    def train_on_batch(self, x, y=None):
+        t = self.trainer
+        rt = self.rt
+        if self.kind == "disc":
+            if t.wiring == "gan2":
+                hr, fake = x
+                loss = t.disc_step(E.to_device_nchw(rt, hr), E.to_device_nchw(rt, fake))
+            else:
+                xs = E.to_device_nchw(rt, x)
+                yv = np.asarray(y).reshape(-1)
+                nb = int((yv > 0).sum())
+                if not (np.all(yv[:nb] == 1) and np.all(yv[nb:] == -1)):
+                    raise NotImplementedError("v1 discriminator targets must be (+1...,-1...) as in train_gan.py:309-313")
+                loss = t.disc_step(xs[:nb], xs[nb:])
+            return t.disc_loss_value(loss)
+        if self.kind == "gan":
+            if t.wiring == "gan2":
+                lr, hr = x
+            else:
+                lr, hr = x, (y[0] if isinstance(y, (list, tuple)) else y)
+            content, adv = t.gan_step(E.to_device_nchw(rt, lr), E.to_device_nchw(rt, hr))
+            return t.gan_loss_values(content, adv)
+        raise NotImplementedError("gen_train.train_on_batch is never called by the reference's GAN loop; "
+                                  "use compile_training_model for generator-only training")
+
+    def train_step(self, lr, hr):
+        """fused loop body (extension): NHWC arrays in, four python floats out."""
+        rt = self.rt
+        return self.trainer.train_step(E.to_device_nchw(rt, lr), E.to_device_nchw(rt, hr))
+
+
+def _make(generator, discriminator, wiring, content_loss, content_loss_weight, losses, discriminator_loss_weight,
+          optimizer, process_group):
+    trainer = GanTrainer(generator, discriminator, wiring, _content_kind(content_loss), content_loss_weight, losses,
+                         discriminator_loss_weight, optimizer, process_group)
+    discriminator.trainable = False     # state the reference leaves behind (model.py:1040,1101)
+    return (TrainingModel(trainer, "gen", "generator_training_model"),
+            TrainingModel(trainer, "disc", "discriminator_training_model"),
+            TrainingModel(trainer, "gan", "gan_training_model"))
+
+
+def make_and_compile_gan(generator, discriminator, input_shape, output_shape, content_loss, content_loss_weight,
+                         discriminator_loss, discriminator_loss_weight, optimizer=_DEFAULT_ADAM, process_group=None):
+    """model.py:1017-1051 (v1 wiring; discriminator_loss must be ``wasserstein_loss``)."""
+    if discriminator_loss is not wasserstein_loss:
+        raise NotImplementedError("v1 wiring is implemented for discriminator_loss=wasserstein_loss (train_gan.py:267)")
+    _check_shapes(generator, discriminator, input_shape, output_shape)
+    return _make(generator, discriminator, "v1", content_loss, content_loss_weight, None, discriminator_loss_weight,
+                 optimizer, process_group)
+
+
+def make_and_compile_gan2(generator, discriminator, input_shape, output_shape, content_loss, content_loss_weight,
+                          discriminator_losses, discriminator_loss_weight, optimizer=_DEFAULT_ADAM, process_group=None):
+    """model.py:1057-1125.  ``discriminator_losses`` is a zero-argument factory, called twice like the
+    reference does (:1085,:1110)."""
+    _check_shapes(generator, discriminator, input_shape, output_shape)
+    losses = discriminator_losses()
+    discriminator_losses()
+    if not isinstance(losses, GanLosses):
+        raise TypeError("discriminator_losses() must return a GanLosses instance")
+    return _make(generator, discriminator, "gan2", content_loss, content_loss_weight, losses,
+                 discriminator_loss_weight, optimizer, process_group)
+
+
+def _check_shapes(generator, discriminator, input_shape, output_shape):
+    if tuple(input_shape) != tuple(generator._in_shape):
+        raise ValueError("input_shape %s does not match the generator's %s" % (tuple(input_shape), generator._in_shape))
+    if tuple(output_shape) != tuple(discriminator._in_shape):
+        raise ValueError("output_shape %s does not match the discriminator's %s" % (tuple(output_shape), discriminator._in_shape))
+
+
+class _GeneratorOnlyTrainer:
+    def __init__(self, upscaler, kind, optimizer):
+        self.G, self.kind, self.opt = upscaler, kind, optimizer
+        self.slots = _Slots(upscaler)
+
+
+class GeneratorTrainingModel:
+    """compile_training_model(upscaler, loss) (model.py:1130-1137): generator-only training with the
+    pixel loss."""
+
+    def __init__(self, upscaler, loss, optimizer):
+        self.G, self.kind, self.opt = upscaler, _content_kind(loss), optimizer
+        self.slots = _Slots(upscaler)
+        self.rt = upscaler.rt
+        self.name = "upscaler_training_model"
+
+    def predict(self, x, batch_size=32):
+        return self.G.predict(x, batch_size)
+
+    def train_on_batch(self, x, y):
+        rt, G = self.rt, self.G
+        lr, hr = E.to_device_nchw(rt, x), E.to_device_nchw(rt, y)
+        fake, tape = G.forward(lr, True)
+        val, dfake = rt.empty(1), rt.empty(*fake.shape)
+        ws, wsn = rt.workspace(rt.lib.vcg_mean_reduce_workspace_bytes(fake.numel()))
+        L.check(rt.lib.vcg_pixel_loss(fake.data_ptr(), hr.data_ptr(), fake.numel(),
+                                      L.LOSS_MSE if self.kind == "mse" else L.LOSS_MAE, 1.0, val.data_ptr(), dfake.data_ptr(),
+                                      ws, wsn, rt.stream), "vcg_pixel_loss")
+        G.backward(tape, dfake, 0)
+        ps = G.ps
+        L.check(rt.lib.vcg_adam_keras_multi(ps.params.data_ptr(), ps.grads.data_ptr(), self.slots.m.data_ptr(),
+                                            self.slots.v.data_ptr(), ps.n_trainable, float(self.opt.lr_t()),
+                                            float(self.opt.beta_1), float(self.opt.beta_2), float(self.opt.epsilon), rt.stream),
+                "vcg_adam_keras_multi")
+        self.opt.iterations += 1
+        G.refresh()
+        return float(val.item())
+
+
+def compile_training_model(upscaler, loss, optimizer=_DEFAULT_ADAM):
+    """model.py:1130-1137"""
+    return GeneratorTrainingModel(upscaler, loss, optimizer)
