@@ -1,0 +1,196 @@
+"""Headline benchmark: up-scaled frames/s of the GAN train step at 256->512 (BASELINE.json).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1], "C2"): generator make_upscaler_orig((512,512,3), kernel_size=3,
+upscale_factor=2, res_block_num=9) + 70x70 PatchGAN, fp32, batch 8 frames per GPU (weak scaling),
+make_and_compile_gan2 wiring with WassersteinLosses, pixel-MSE content loss, loss weights 1 and 1e-5.
+A step is one iteration of the reference loop body (train_gan3.py:346-354): gen_train.predict ->
+disc_train.train_on_batch -> gan_train.train_on_batch, on synthetic frames already resident in HBM.
+
+Prints ONE JSON line (rank 0).  Extra objects:
+  roofline     -- the dominant kernel (3x3 64->64 trunk convolution, forward and its data gradient run
+                  the same kernel): algorithmic FLOPs per launch / mean launch duration measured with HIP
+                  events on the launch stream inside the timed region, against the fp32 MFMA peak.
+  cpu_baseline -- the CPU oracle (a port: the Keras/TF reference cannot run offline) timed on this
+                  host's cores on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, "video-cycle_gan-upscaling_amd")
+for p in (ROOT, PKG):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+PEAK_F32_MFMA_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+METRIC = "upscaled frames/s (train step, G+D fwd+bwd) at 256->512"
+
+
+class KernelProf:
+    def __init__(self, tags):
+        self.tags = set(tags)
+        self.events = {}
+
+    def mean_ms(self, tags):
+        tot, cnt = 0.0, 0
+        for t in tags:
+            for e0, e1 in self.events.get(t, []):
+                tot += e0.elapsed_time(e1)
+                cnt += 1
+        return (tot / cnt if cnt else None), cnt
+
+
+def _host_cores():
+    """cores this process may actually use: cgroup CPU quota if set, else the affinity mask (a GPU box
+    exposes all host cores but grants a share -- 16 per GPU on this pool)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(float(q) / float(p))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, int(os.environ.get("VCG_CPU_THREADS", "16"))))
+
+
+def cpu_baseline(res_blocks, sample_batch, lr_hw):
+    """One train step of the CPU oracle (torch CPU fp32, all host cores) on `sample_batch` frames of the
+    same models / frame size."""
+    import numpy as np
+    import torch
+    from oracle import models as OM, train as OT
+    torch.set_num_threads(_host_cores())
+    h = lr_hw
+    gw = OM.to_torch(OM.init_upscaler_orig((2 * h, 2 * h, 3), 3, 64, 2, res_blocks, seed=7))
+    dw = OM.to_torch(OM.init_discriminator_patchgan_70((2 * h, 2 * h, 3), seed=11))
+    orc = OT.GanOracle(lambda w, x, t: OM.upscaler_orig_forward(w, x, t, res_blocks, 2), gw,
+                       lambda w, x, t: OM.discriminator_patchgan_70_forward(w, x, t), dw,
+                       discriminator_loss_weight=1e-5)
+    g = torch.Generator().manual_seed(1234)
+    lr = torch.randint(0, 256, (sample_batch, h, h, 3), generator=g).float() / 127.5 - 1
+    hr = torch.randint(0, 256, (sample_batch, 2 * h, 2 * h, 3), generator=g).float() / 127.5 - 1
+    t0 = time.perf_counter()
+    orc.train_step(lr, hr)
+    dt = time.perf_counter() - t0
+    return {"value": round(sample_batch / dt, 4), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "1 train step (predict + D step + G step) of the torch-CPU fp32 oracle on %d frame(s) %dx%d->%dx%d, "
+                      "same models; %.1f s" % (sample_batch, h, h, 2 * h, 2 * h, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=8, help="frames per GPU")
+    ap.add_argument("--lr-size", type=int, default=256, help="low-res frame edge (output is 2x)")
+    ap.add_argument("--res-blocks", type=int, default=9)
+    ap.add_argument("--disc", default="patchgan", choices=["patchgan", "simple"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-batch", type=int, default=2)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from upscaler import _dist
+    from upscaler import _engine as E
+    from upscaler import data as PD
+    from upscaler import model as PM
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d"
+                         % (args.gpus, world, args.gpus))
+    torch.cuda.set_device(local_rank)
+    group = _dist.init_from_env("nccl") if world > 1 else None
+
+    h = args.lr_size
+    G = PM.make_upscaler_orig((2 * h, 2 * h, 3), kernel_size=3, upscale_factor=2, res_block_num=args.res_blocks, seed=7)
+    D = (PM.make_discriminator_patchgan_70((2 * h, 2 * h, 3), seed=11) if args.disc == "patchgan"
+         else PM.make_discriminator_simple_512((2 * h, 2 * h, 3), seed=11))
+    if group is not None:                     # identical replicas: broadcast rank 0's weights
+        for m in (G, D):
+            _dist.broadcast_(m.ps.params, group)
+            _dist.broadcast_(m.ps.state, group)
+            m.refresh()
+    gen_train, disc_train, gan_train = PM.make_and_compile_gan2(
+        G, D, (h, h, 3), (2 * h, 2 * h, 3), "mse", 1.0, lambda: PM.WassersteinLosses(), 1e-5, optimizer=PM.Adam(),
+        process_group=group)
+    trainer = gan_train.trainer
+    rt = E.Runtime.get()
+
+    # synthetic frames: uint8 U{0..255} -> v/127.5-1 (data.py:266-270), resident in HBM before timing
+    g1 = torch.Generator().manual_seed(1234 + rank)
+    g2 = torch.Generator().manual_seed(4321 + rank)
+    lr = PD.frames_u8_to_device(torch.randint(0, 256, (args.batch, h, h, 3), generator=g1, dtype=torch.uint8))
+    hr = PD.frames_u8_to_device(torch.randint(0, 256, (args.batch, 2 * h, 2 * h, 3), generator=g2, dtype=torch.uint8))
+
+    def sync():
+        torch.cuda.synchronize()
+        if group is not None:
+            dist.barrier(group=group)
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        trainer.train_step(lr, hr)
+    dom_tags = ("trunk_conv", "trunk_conv_dgrad")
+    rt.prof = KernelProf(dom_tags)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        losses = trainer.train_step(lr, hr)
+    sync()
+    dt = time.perf_counter() - t0
+    prof, rt.prof = rt.prof, None
+
+    dt_t = torch.tensor([dt], dtype=torch.float64, device=rt.device)
+    if group is not None:
+        dist.all_reduce(dt_t, op=dist.ReduceOp.MAX, group=group)
+    dt = float(dt_t.item())
+    frames = args.batch * world * args.steps
+
+    # roofline of the dominant kernel
+    mean_ms, launches = prof.mean_ms(dom_tags)
+    flop_per_launch = 2.0 * (64 * 64 * 9) * (h * h) * args.batch           # 2 * MAC/pixel * pixels * frames
+    roof = None
+    if mean_ms:
+        ach = flop_per_launch / (mean_ms * 1e-3) / 1e12
+        roof = {"bound": "mfma", "kernel": "conv_fwd_kernel<3,3,1,8> (64->64 3x3 trunk conv, forward + dgrad)",
+                "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                "launches_timed": launches, "mean_launch_ms": round(mean_ms, 4),
+                "flop_per_launch": flop_per_launch}
+
+    if rank == 0:
+        out = {
+            "metric": METRIC, "value": round(frames / dt, 3), "unit": "frames/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "C2: make_upscaler_orig((%d,%d,3),k=3,x2,res=%d) + %s, batch %d/GPU, "
+                                   "gan2 wiring, Wasserstein + pixel-MSE, faithful 3-call step incl. predict pass"
+                                   % (2 * h, 2 * h, args.res_blocks, "PatchGAN-70" if args.disc == "patchgan" else "simple_512",
+                                      args.batch),
+                       "global_batch": args.batch * world, "frame": "%dx%d->%dx%d" % (h, h, 2 * h, 2 * h),
+                       "parallelism": "dp%d" % world},
+            "last_losses": [round(float(v), 6) for v in losses],
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.res_blocks, args.cpu_sample_batch, h)
+        print(json.dumps(out), flush=True)
+    if group is not None:
+        dist.barrier(group=group)
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

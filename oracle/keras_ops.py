@@ -44,7 +44,7 @@ def conv2d(x, w_hwio, b, stride=1, padding="same"):
     An int padding p is symmetric explicit zero padding (used only by the PatchGAN extension,
     which has no reference counterpart -- SURVEY.md section 8 row a11)."""
     kh, kw = w_hwio.shape[0], w_hwio.shape[1]
-    w = w_hwio.permute(3, 2, 0, 1)                       # -> (out, in, kh, kw)
+    w = w_hwio.permute(3, 2, 0, 1).contiguous()          # -> (out, in, kh, kw)
     if padding == "same":
         _, pt, pb = same_pads(x.shape[2], kh, stride)
         _, pl, pr = same_pads(x.shape[3], kw, stride)
@@ -62,7 +62,7 @@ def conv2d_transpose_same(x, w_hwoi, b, stride=2):
     out = in*stride; equals the full transposed convolution (length (in-1)*s + k) cropped by
     before = floor((k-s)/2), after = ceil((k-s)/2)  (SURVEY.md Appendix A)."""
     kh, kw = w_hwoi.shape[0], w_hwoi.shape[1]
-    w = w_hwoi.permute(3, 2, 0, 1)                       # (in, out, kh, kw) == torch conv_transpose
+    w = w_hwoi.permute(3, 2, 0, 1).contiguous()          # (in, out, kh, kw) == torch conv_transpose
     full = F.conv_transpose2d(x, w, None, stride=stride)
     oh, ow = x.shape[2] * stride, x.shape[3] * stride
     ct = max(kh - stride, 0) // 2

@@ -72,7 +72,7 @@ def to_torch(w, dtype=torch.float32, requires_grad=False):
 # generator: make_upscaler_orig (model.py:267-295)
 # ----------------------------------------------------------------------------------------------
 def init_upscaler_orig(output_image_shape, kernel_size=5, filters=64, upscale_factor=4,
-                       res_block_num=16, seed=7):
+                       res_block_num=16, seed=7, norm="batch"):
     rng = np.random.RandomState(seed)
     k = kernel_size
     w = OrderedDict()
@@ -81,12 +81,15 @@ def init_upscaler_orig(output_image_shape, kernel_size=5, filters=64, upscale_fa
     for i in range(res_block_num):
         n = "res_block/%d" % i
         _conv_w(w, rng, n + "/conv_pre", k, k, filters, filters)
-        _bn_w(w, n + "/batch_norm_pre", filters)
+        if norm == "batch":
+            _bn_w(w, n + "/batch_norm_pre", filters)
         _prelu_w(w, n + "/prelu", filters)
         _conv_w(w, rng, n + "/conv_post", k, k, filters, filters)
-        _bn_w(w, n + "/batch_norm_post", filters)
+        if norm == "batch":
+            _bn_w(w, n + "/batch_norm_post", filters)
     _conv_w(w, rng, "prefinal/conv2d", k, k, filters, 64)         # 64 hard-coded: model.py:283
-    _bn_w(w, "prefinal/batch_norm", 64)
+    if norm == "batch":
+        _bn_w(w, "prefinal/batch_norm", 64)
     cin = 64
     for i in range(int(math.log(upscale_factor, 2))):
         _convt_w(w, rng, "upscaling/%d/block/conv_transp" % i, k, k, cin, 256)  # 256: model.py:288
@@ -95,13 +98,15 @@ def init_upscaler_orig(output_image_shape, kernel_size=5, filters=64, upscale_fa
     return w
 
 
-def upscaler_orig_forward(w, x_nhwc, training, res_block_num, upscale_factor, taps=None):
+def upscaler_orig_forward(w, x_nhwc, training, res_block_num, upscale_factor, taps=None, norm="batch"):
     """x_nhwc: [N,h,w,3] -> ([N,h*f,w*f,3], bn_updates).  ``training`` selects batch vs moving BN
     statistics (Keras learning phase: predict=0, train_on_batch=1).  ``taps`` (optional dict)
     receives named NCHW intermediates for kernel-level parity tests."""
     upd = OrderedDict()
 
     def bn(x, name):
+        if norm == "instance":          # north_star extension (no reference counterpart)
+            return K.instancenorm(x)
         y, mm, mv = K.batchnorm(x, w[name + "/gamma"], w[name + "/beta"], w[name + "/moving_mean"],
                                 w[name + "/moving_variance"], training)
         if training:

@@ -33,9 +33,9 @@ class SharedAdam:
 
 
 class _Slots:
-    def __init__(self, weights):
+    def __init__(self, weights, v0=0.0):
         self.m = OrderedDict((k, torch.zeros_like(v)) for k, v in weights.items() if is_trainable(k))
-        self.v = OrderedDict((k, torch.zeros_like(v)) for k, v in weights.items() if is_trainable(k))
+        self.v = OrderedDict((k, torch.full_like(v, v0)) for k, v in weights.items() if is_trainable(k))
 
 
 def content_loss_value(kind, y_true, y_pred):
@@ -53,14 +53,17 @@ class GanOracle:
 
     def __init__(self, g_forward, g_w, d_forward, d_w, wiring="gan2", content="mse",
                  content_loss_weight=1.0, losses="wass", loss_activation="log-sigm",
-                 discriminator_loss_weight=1e-5, optimizer=None):
+                 discriminator_loss_weight=1e-5, optimizer=None, adam_v0=0.0):
+        """adam_v0: initial value of Adam's second-moment slots.  Keras starts at 0, which makes the first
+        updates sign-like (|step| = lr whatever the gradient) and any fp32-vs-fp64 comparison after one step
+        chaotic; parity runs that look past the first update prime the slots instead (tests only)."""
         self.g_forward, self.d_forward = g_forward, d_forward
         self.g_w, self.d_w = g_w, d_w
         self.wiring, self.content = wiring, content
         self.cw, self.dw = content_loss_weight, discriminator_loss_weight
         self.losses, self.loss_activation = losses, loss_activation
         self.opt = optimizer or SharedAdam()
-        self.d_slots, self.g_slots = _Slots(d_w), _Slots(g_w)
+        self.d_slots, self.g_slots = _Slots(d_w, adam_v0), _Slots(g_w, adam_v0)
         self.last_d_grads = None
         self.last_g_grads = None
         self.last_fake_train = None

@@ -1,0 +1,94 @@
+"""world_size-2 data parallelism on CPU (gloo): the product's bucket all-reduce helpers (upscaler._dist)
+drive the CPU oracle's gradients; a 2-rank DP step must equal the 1-rank step on the concatenated batch
+(instance-norm models, so that per-replica statistics do not change the maths -- SURVEY.md section 8e)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "video-cycle_gan-upscaling_amd")
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _grads(lr, hr):
+    """flat G-gradient of cw*mse + dw*mean(D(G(x))) for the instance-norm generator + PatchGAN"""
+    from oracle import models as M
+    from oracle import train as T
+    gw = M.to_torch(M.init_upscaler_orig((32, 32, 3), 3, 64, 2, 1, seed=7, norm="instance"), torch.float64, requires_grad=True)
+    dw = M.to_torch(M.init_discriminator_patchgan_70((32, 32, 3), seed=11), torch.float64)
+    fake, _ = M.upscaler_orig_forward(gw, lr, True, 1, 2, norm="instance")
+    d, _ = M.discriminator_patchgan_70_forward(dw, fake, True)
+    loss = T.content_loss_value("mse", hr, fake) + 1e-2 * d.mean()
+    names = [k for k, v in gw.items() if v.requires_grad]
+    gs = torch.autograd.grad(loss, [gw[k] for k in names])
+    return torch.cat([g.reshape(-1) for g in gs]), float(d.mean())
+
+
+def _worker(rank, world, port, q):
+    for p in (ROOT, PKG):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(2)
+    from upscaler import _dist
+    group = _dist.init_from_env("gloo")
+    rng = np.random.RandomState(5)
+    lr = torch.tensor(rng.randint(0, 256, (4, 16, 16, 3)) / 127.5 - 1)
+    hr = torch.tensor(rng.randint(0, 256, (4, 32, 32, 3)) / 127.5 - 1)
+    lo, hi = _dist.shard_batch(4, group)
+    flat, dmean = _grads(lr[lo:hi], hr[lo:hi])
+    _dist.allreduce_mean(flat, group)
+    m = torch.tensor([dmean], dtype=torch.float64)
+    _dist.allreduce_mean(m, group)
+    w = torch.full((5,), float(rank))
+    _dist.broadcast_(w, group, src=0)
+    if rank == 0:
+        full, dfull = _grads(lr, hr)
+        q.put((float((flat - full).abs().max()), float(full.abs().max()), abs(float(m) - dfull), (lo, hi)))
+    else:
+        q.put((float(w.abs().max()), (lo, hi)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_dp2_equals_single_rank_on_concatenated_batch():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    r0 = [r for r in res if len(r) == 4][0]
+    r1 = [r for r in res if len(r) == 2][0]
+    err, scale, dmean_err, shard0 = r0
+    assert err < 1e-10 * max(scale, 1.0), (err, scale)
+    assert dmean_err < 1e-12
+    assert shard0 == (0, 2) and r1[1] == (2, 4)
+    assert r1[0] == 0.0                       # broadcast from rank 0 overwrote rank 1's buffer
+
+
+def test_shard_batch_single_process():
+    for p in (ROOT, PKG):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from upscaler import _dist
+    assert _dist.shard_batch(8, None) == (0, 8)
+    t = torch.ones(3)
+    assert _dist.allreduce_mean(t, None) is t

@@ -1,0 +1,153 @@
+"""CPU-only checks of the host side: the C-ABI library loads and exports every symbol include/vcg.h
+declares, the Python mirror keeps the reference's names and signatures, and the product path fails
+loudly without a GPU (no CPU fallback, no oracle import)."""
+import inspect
+import math
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "video-cycle_gan-upscaling_amd")
+
+
+@pytest.fixture(scope="module")
+def built():
+    import __graft_entry__ as g
+    g.build()
+    from upscaler import _lib
+    return _lib
+
+
+def _declared_in_header():
+    src = open(os.path.join(ROOT, "include", "vcg.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return set(re.findall(r"\b(vcg_[a-z0-9_]+)\s*\(", src))
+
+
+def test_library_exports_every_declared_symbol(built):
+    lib = built.load()
+    declared = _declared_in_header()
+    assert declared == set(built.SIGNATURES), declared ^ set(built.SIGNATURES)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert b"gfx950" in lib.vcg_version()
+    assert lib.vcg_error_string(-3).decode().startswith("kernel size")
+
+
+def test_workspace_queries_and_argument_errors_without_gpu(built):
+    """pure host logic of the ABI: size queries and invalid-argument codes need no device"""
+    import ctypes
+    lib = built.load()
+    d = built.ConvDesc(8, 64, 256, 256, 64, 256, 256, 3, 3, 1, 1, 1)
+    ws = lib.vcg_conv2d_wgrad_workspace_bytes(ctypes.byref(d))
+    assert 0 < ws < (1 << 30)
+    assert lib.vcg_norm_stats_workspace_bytes(8, 64, 65536, 0) > 0
+    assert lib.vcg_conv2d_fwd(None, None, None, None, None, None) == -1           # VCG_E_NULL
+    bad = built.ConvDesc(8, 64, 256, 256, 64, 256, 256, 3, 3, 3, 1, 1)            # stride 3
+    assert lib.vcg_conv2d_wgrad_workspace_bytes(ctypes.byref(bad)) == 0
+    with pytest.raises(ValueError):
+        built.check(-2, "x")
+
+
+def test_reference_signatures_are_mirrored():
+    from upscaler import model as PM
+
+    def params(f):
+        return [(p.name, p.default) for p in inspect.signature(f).parameters.values()]
+
+    # upscaling/upscaler/model.py:267
+    assert params(PM.make_upscaler_orig)[:5] == [("output_image_shape", inspect._empty), ("kernel_size", 5), ("filters", 64),
+                                                 ("upscale_factor", 4), ("res_block_num", 16)]
+    # :836, :901
+    assert params(PM.make_discriminator_simple_512)[:2] == [("input_shape", inspect._empty), ("activation", "none")]
+    assert params(PM.make_discriminator_thin_512)[:2] == [("input_shape", inspect._empty), ("activation", "none")]
+    # :1017-1027, :1057-1067
+    names = [n for n, _ in params(PM.make_and_compile_gan)]
+    assert names[:9] == ["generator", "discriminator", "input_shape", "output_shape", "content_loss", "content_loss_weight",
+                         "discriminator_loss", "discriminator_loss_weight", "optimizer"]
+    names = [n for n, _ in params(PM.make_and_compile_gan2)]
+    assert names[:9] == ["generator", "discriminator", "input_shape", "output_shape", "content_loss", "content_loss_weight",
+                         "discriminator_losses", "discriminator_loss_weight", "optimizer"]
+    assert [n for n, _ in params(PM.compile_training_model)] == ["upscaler", "loss", "optimizer"]
+    assert [n for n, _ in params(PM.wasserstein_loss)] == ["y_true", "y_pred"]
+    # :166-261
+    assert params(PM.GanLosses.__init__)[1:] == [("loss_activation", "log-sigm"), ("real_output", None), ("fake_output", None)]
+    for cls in (PM.WassersteinLosses, PM.RelativisticLosses):
+        for prop in ("real_output", "fake_output", "discriminator_loss", "generator_loss"):
+            assert isinstance(getattr(cls, prop), property)
+    for meth in ("predict", "save"):
+        assert hasattr(PM.Model, meth)
+    for meth in ("predict", "train_on_batch"):
+        assert hasattr(PM.TrainingModel, meth)
+    from upscaler import data as PD
+    for fn in ("convert_array_to_image", "convert_image_to_array", "convert_image_series_to_array"):
+        assert hasattr(PD, fn)
+
+
+def test_host_side_losses_and_optimizer():
+    from upscaler import model as PM
+    w = PM.WassersteinLosses()
+    w.real_output, w.fake_output = np.array([[1.0], [3.0]]), np.array([[0.5], [0.5]])
+    assert w.discriminator_loss(None, None) == 1.5 and w.generator_loss(None, None) == 0.5
+    r = PM.RelativisticLosses(loss_activation="log-sigm", real_output=np.array([2.0]), fake_output=np.array([0.0]))
+    assert abs(r.discriminator_loss(None, None) - math.log(1 / (1 + math.exp(-2.0)))) < 1e-12
+    assert abs(r.generator_loss(None, None) - math.log(1 / (1 + math.exp(2.0)))) < 1e-12
+    assert PM.RelativisticLosses(loss_activation="log").loss_activation(0.3) == 0.3        # unknown name -> identity (Appendix D)
+    for name in ("sigmoid", "log-sigm", "tanh", "bi-log", "none"):
+        for x in (-2.3, -0.1, 0.4, 3.0):
+            v, g = PM._act_value_and_grad(name, x)
+            h = 1e-6
+            fd = (PM._act_value_and_grad(name, x + h)[0] - PM._act_value_and_grad(name, x - h)[0]) / (2 * h)
+            assert abs(g - fd) < 1e-6, (name, x)
+    assert PM.wasserstein_loss(np.array([1, -1]), np.array([[2.0], [4.0]])) == -1.0
+    a = PM.Adam()
+    assert abs(a.lr_t() - 1e-3 * math.sqrt(1 - 0.999) / (1 - 0.9)) < 1e-15
+    assert PM._content_kind("mean_squared_error") == "mse" and PM._content_kind(PM.PixelLoss("mae").loss) == "mae"
+    with pytest.raises(NotImplementedError):
+        PM._content_kind(lambda a, b: 0)
+
+
+def test_padding_arithmetic_matches_oracle():
+    from oracle import keras_ops as K
+    from upscaler import _engine as E
+    for size in (2, 5, 64, 135, 240, 512, 1080):
+        for k in (3, 4, 5, 9):
+            for s in (1, 2):
+                assert E.same_pads(size, k, s) == K.same_pads(size, k, s)
+
+
+def test_data_value_map_host():
+    from upscaler import data as PD
+    u8 = np.random.RandomState(0).randint(0, 256, (2, 5, 6, 3)).astype(np.uint8)
+    a = PD.convert_image_series_to_array(list(u8))
+    assert a.dtype == np.float64 and np.array_equal(a, u8 / 127.5 - 1)
+    img = PD.convert_array_to_image(a[0])
+    assert np.array_equal(np.array(img), u8[0])
+
+
+def test_product_fails_loudly_without_gpu_and_never_imports_oracle():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from upscaler import model as PM\n"
+            "try:\n"
+            "    PM.make_upscaler_orig((128,128,3), 3, 64, 2, 1)\n"
+            "    print('NOFAIL')\n"
+            "except RuntimeError as e:\n"
+            "    print('RAISED', 'oracle' in sys.modules)\n") % PKG
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT).stdout
+    assert "RAISED False" in out, out
+
+
+def test_product_sources_do_not_reference_the_oracle():
+    for dirpath, _, files in os.walk(PKG):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle", txt, flags=re.M), f

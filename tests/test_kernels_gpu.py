@@ -248,7 +248,8 @@ def test_adam_losses_layout(rt):
         (0.7 * lv).backward()
         out, da = rt.empty(1), rt.empty(*a.shape)
         ws, wsn = rt.workspace(lib.vcg_mean_reduce_workspace_bytes(a.numel()))
-        L.check(lib.vcg_pixel_loss(a.float().to(rt.device).data_ptr(), b.float().to(rt.device).data_ptr(), a.numel(), code, 0.7,
+        a_dev, b_dev = a.float().to(rt.device), b.float().to(rt.device)      # keep the buffers alive
+        L.check(lib.vcg_pixel_loss(a_dev.data_ptr(), b_dev.data_ptr(), a.numel(), code, 0.7,
                                    out.data_ptr(), da.data_ptr(), ws, wsn, rt.stream), "pixel_loss")
         assert abs(out.item() - lv.item()) < 1e-5 * abs(lv.item()) + 1e-7
         assert rel_err(da, ar.grad) < 1e-5

@@ -1,0 +1,112 @@
+"""Pins the oracle against every known answer the reference's own notebooks hold for this path
+ -- shapes, parameter counts, value map.  The reference has no numeric golden
+vectors ("parity unpinned"), so these are the only reference-derived pins."""
+import numpy as np
+import torch
+
+from oracle import data as OD
+from oracle import keras_ops as K
+from oracle import models as M
+
+
+def _n(w):
+    return int(sum(int(np.prod(v.shape)) for v in w.values()))
+
+
+def test_cnn_test_cell12_shapes_and_params():
+    # upscaling/cnn_test.ipynb cell 12: Input (135,240,3) -> Conv2D(1,k3,s2,same) -> (68,120,1), 28 params
+    w, rng = {}, np.random.RandomState(0)
+    M._conv_w(w, rng, "c", 3, 3, 3, 1)
+    assert _n(w) == 28
+    x = torch.zeros(1, 3, 135, 240)
+    y = K.conv2d(x, torch.tensor(w["c/kernel"]), torch.tensor(w["c/bias"]), 2, "same")
+    assert tuple(y.shape[2:]) == (68, 120)
+    # 4x Conv2DTranspose(1,k3,s2,same): (136,240) -> (272,480) -> (544,960) -> (1088,1920), 10 params each
+    total = 28
+    for expect in ((136, 240), (272, 480), (544, 960), (1088, 1920)):
+        wt = {}
+        M._convt_w(wt, rng, "t", 3, 3, 1, 1)
+        assert _n(wt) == 10
+        total += 10
+        y = K.conv2d_transpose_same(y, torch.tensor(wt["t/kernel"]), torch.tensor(wt["t/bias"]), 2)
+        assert tuple(y.shape[2:]) == expect
+    assert total == 68
+    # cell 8: Cropping2D((4,0)) -> (1080,1920)
+    assert ((1088 - 1080) // 2, (1920 - 1920) // 2) == (4, 0)
+
+
+def test_cnn_test_cell18_param_counts():
+    rng = np.random.RandomState(0)
+
+    def conv(k, cin, cout):
+        w = {}
+        M._conv_w(w, rng, "c", k, k, cin, cout)
+        return _n(w)
+
+    def convt(k, cin, cout):
+        w = {}
+        M._convt_w(w, rng, "c", k, k, cin, cout)
+        return _n(w)
+
+    assert conv(9, 3, 128) == 31232
+    w = {}
+    M._prelu_w(w, "p", 128)
+    assert _n(w) == 128                      # PReLU(shared_axes=[1,2]) on 128 channels
+    assert conv(3, 128, 128) == 147584
+    assert conv(3, 128, 256) == 295168
+    assert conv(3, 256, 256) == 590080
+    assert conv(3, 256, 512) == 1180160
+    assert conv(3, 512, 512) == 2359808
+    assert convt(3, 512, 512) == 2359808
+    assert conv(3, 768, 256) == 1769728
+    assert conv(9, 128, 3) == 31107
+    # Conv2DTranspose(512,k3,s2): (34,60) -> (68,120) -> (136,240)
+    y = torch.zeros(1, 2, 34, 60)
+    wt = torch.zeros(3, 3, 2, 2)
+    y = K.conv2d_transpose_same(y, wt, None, 2)
+    assert tuple(y.shape[2:]) == (68, 120)
+    assert tuple(K.conv2d_transpose_same(y, wt, None, 2).shape[2:]) == (136, 240)
+
+
+def test_same_padding_rule():
+    assert K.same_pads(135, 3, 2) == (68, 1, 1)
+    assert K.same_pads(240, 3, 2) == (120, 0, 1)      # even input, k3 s2: pad (0,1)
+    assert K.same_pads(512, 5, 2) == (256, 1, 2)
+    assert K.same_pads(256, 9, 1) == (256, 4, 4)
+    assert K.same_pads(256, 5, 1) == (256, 2, 2)
+
+
+def test_model_param_counts_appendix_b():
+    assert M.count_params(M.init_upscaler_orig((128, 128, 3), 3, 64, 2, 6)) == 709379
+    assert M.count_params(M.init_upscaler_orig((128, 128, 3), 5, 64, 2, 6)) == 1823491
+    assert M.count_params(M.init_upscaler_orig((512, 512, 3), 3, 64, 2, 9)) == 932675
+    assert M.count_params(M.init_upscaler_orig((512, 512, 3), 5, 64, 2, 9)) == 2440003
+    assert M.count_params(M.init_upscaler_orig((512, 512, 3), 5, 64, 4, 16)) == 5517187
+    assert M.count_params(M.init_discriminator_512((128, 128, 3), "simple")) == 13926465
+    assert M.count_params(M.init_discriminator_512((512, 512, 3), "simple")) == 15499329
+    assert M.count_params(M.init_discriminator_512((1080, 1920, 3), "simple")) == 34373697
+    assert M.count_params(M.init_discriminator_512((512, 512, 3), "thin")) == 1675457
+    assert M.count_params(M.init_discriminator_patchgan_70((512, 512, 3))) == 2764737
+
+
+def test_gan_test_output_shapes():
+    # upscaling/gan_test.ipynb cells 17-18: discriminator output (N,1) float32; generator x2 upscale
+    dw = M.to_torch(M.init_discriminator_512((128, 128, 3), "thin"))
+    x = torch.zeros(3, 128, 128, 3)
+    y, _ = M.discriminator_512_forward(dw, x, False)
+    assert tuple(y.shape) == (3, 1) and y.dtype == torch.float32
+    gw = M.to_torch(M.init_upscaler_orig((64, 64, 3), 3, 64, 2, 1))
+    g, _ = M.upscaler_orig_forward(gw, torch.zeros(2, 32, 32, 3), False, 1, 2)
+    assert tuple(g.shape) == (2, 64, 64, 3)
+    p, _ = M.discriminator_patchgan_70_forward(M.to_torch(M.init_discriminator_patchgan_70((512, 512, 3))), torch.zeros(1, 512, 512, 3), True)
+    assert tuple(p.shape) == (1, 62, 62, 1)
+
+
+def test_value_map_data_py():
+    # upscaling/upscaler/data.py:253-270 and minitrain_test.ipynb cells 7-8 (NHWC batches)
+    u8 = np.arange(256, dtype=np.uint8).reshape(1, 16, 16, 1).repeat(3, axis=3)
+    a = OD.convert_uint8_to_array(u8)
+    assert a.dtype == np.float64 and a.shape == (1, 16, 16, 3)
+    assert a.min() == -1.0 and a.max() == 1.0
+    assert np.array_equal(a[0, :, :, 0].reshape(-1), np.arange(256) / 127.5 - 1)
+    assert np.array_equal(OD.convert_array_to_uint8(a), u8)
