@@ -21,9 +21,9 @@ CASES = {
     "c1": dict(batch=1, res=6, k=3, disc="simple", losses="wass", dw=1e-5, steps=2),
     # batch 4 / relativistic loss / thin D: exercises BN statistics and the non-linear loss.  adam_v0 primes
     # Adam's second-moment slots (see oracle/train.py): post-update quantities are then well conditioned
-    "b4_rel": dict(batch=4, res=2, k=3, disc="thin", losses="rel", dw=1e-2, steps=2, adam_v0=1e-8),
+    "b4_rel": dict(batch=4, res=2, k=3, disc="thin", losses="rel", dw=1e-2, steps=2, adam_v0=1.0),
     # the north_star PatchGAN extension
-    "b2_patch": dict(batch=2, res=2, k=3, disc="patch", losses="wass", dw=1e-2, steps=2, adam_v0=1e-8),
+    "b2_patch": dict(batch=2, res=2, k=3, disc="patch", losses="wass", dw=1e-2, steps=2, adam_v0=1.0),
 }
 
 

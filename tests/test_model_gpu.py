@@ -152,7 +152,7 @@ def test_generator_layers_ragged_shapes(rt, shape):
 
 CASES = [("gan2", "wass", "simple", 3), ("gan2", "rel", "thin", 3), ("v1", "wass", "simple", 3), ("gan2", "wass", "patch", 3),
          ("gan2", "wass", "simple", 5)]
-ADAM_V0 = 1e-8
+ADAM_V0 = 1.0
 
 
 def _build_pair(rt, wiring, losses, disc, k, adam_v0, res=2, dwt=1e-2):
@@ -196,7 +196,7 @@ def test_train_step_parity(rt, wiring, losses, disc, k):
     """Two loop-body iterations against the fp64 oracle: the four reported losses of both iterations, every
     weight of G and D after the two Adam updates each, the BN moving statistics and the networks as functions.
 
-    Adam's second-moment slots are primed with 1e-8 in BOTH implementations: with Keras' zero start the first
+    Adam's second-moment slots are primed with 1.0 in BOTH implementations: with Keras' zero start the first
     updates are sign-like (|step| = lr for every weight whatever its gradient), which turns fp32 rounding of
     near-zero gradients into +-lr weight differences and makes any comparison after the first update chaotic
     -- for the product and for an fp32 run of the oracle alike (test_train_step_default_adam_vs_fp32_oracle

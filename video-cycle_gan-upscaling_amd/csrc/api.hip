@@ -9,9 +9,9 @@ int vcg_internal_conv(const float* x, const float* w, float* y, int n, int cin, 
 int vcg_internal_convt(const float* x, const float* w, float* y, int n, int cin, int h, int wd, int cout, int oh,
                        int ow, int k, int cby, int cbx, const vcg_epilogue* ep, hipStream_t st);
 size_t vcg_internal_wgrad_ws(int n, int mtot, int ah, int aw, int jctot, int kh, int kw, int S);
-int vcg_internal_wgrad(const float* A, const float* B, float* dw, int n, int mtot, int ah, int aw, int jctot, int bh,
-                       int bw, int kh, int kw, int S, int pt, int pl_, int flip, int ts, int sm, int sj, void* ws,
-                       size_t ws_bytes, hipStream_t st);
+int vcg_internal_wgrad(const float* A, const float* B, float* dw, float* db, int n, int mtot, int ah, int aw,
+                       int jctot, int bh, int bw, int kh, int kw, int S, int pt, int pl_, int flip, int ts, int sm,
+                       int sj, void* ws, size_t ws_bytes, hipStream_t st);
 
 namespace {
 
@@ -110,12 +110,14 @@ int vcg_conv2d_wgrad(const vcg_conv_desc* d, const float* x, const float* dy, fl
     const int cc = d->cin * d->cout;
     if (d->stride == 1 && d->cout <= 3) {
         // swapped orientation: A = x (m = ci), B = dy (jc = co), flipped taps, pads K-1-p
-        rc = vcg_internal_wgrad(x, dy, dw_hwio, d->n, d->cin, d->h, d->w, d->cout, d->oh, d->ow, d->kh, d->kw, 1,
-                                d->kh - 1 - d->pad_top, d->kw - 1 - d->pad_left, 1, cc, d->cout, 1, ws, ws_bytes, st);
+        rc = vcg_internal_wgrad(x, dy, dw_hwio, nullptr, d->n, d->cin, d->h, d->w, d->cout, d->oh, d->ow, d->kh, d->kw,
+                                1, d->kh - 1 - d->pad_top, d->kw - 1 - d->pad_left, 1, cc, d->cout, 1, ws, ws_bytes, st);
     } else {
-        // normal: A = dy (m = co), B = x (jc = ci);  dw[tap][ci][co]
-        rc = vcg_internal_wgrad(dy, x, dw_hwio, d->n, d->cout, d->oh, d->ow, d->cin, d->h, d->w, d->kh, d->kw,
+        // normal: A = dy (m = co), B = x (jc = ci);  dw[tap][ci][co]; the bias gradient (per-channel sum of
+        // dy) is accumulated from the staged dy tiles inside the same kernel
+        rc = vcg_internal_wgrad(dy, x, dw_hwio, dbias, d->n, d->cout, d->oh, d->ow, d->cin, d->h, d->w, d->kh, d->kw,
                                 d->stride, d->pad_top, d->pad_left, 0, cc, 1, d->cout, ws, ws_bytes, st);
+        dbias = nullptr;
     }
     if (rc) return rc;
     if (dbias) {
@@ -169,7 +171,7 @@ int vcg_conv_transpose2d_wgrad(const vcg_conv_desc* d, const float* x, const flo
     VCG_CHECK_PTR(x); VCG_CHECK_PTR(dy); VCG_CHECK_PTR(dw_hwoi);
     if (d->stride != 2) return VCG_E_UNSUPPORTED;
     // dW[k][co][ci] = sum_i x[ci][i] * dy[co][2i + k - cb]: A = x (m = ci), B = dy (jc = co), stride 2
-    rc = vcg_internal_wgrad(x, dy, dw_hwoi, d->n, d->cin, d->h, d->w, d->cout, d->oh, d->ow, d->kh, d->kw, 2,
+    rc = vcg_internal_wgrad(x, dy, dw_hwoi, nullptr, d->n, d->cin, d->h, d->w, d->cout, d->oh, d->ow, d->kh, d->kw, 2,
                             d->pad_top, d->pad_left, 0, d->cin * d->cout, 1, d->cin, ws, ws_bytes, (hipStream_t)stream);
     if (rc) return rc;
     if (dbias) {

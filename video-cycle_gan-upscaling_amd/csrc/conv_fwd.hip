@@ -16,6 +16,7 @@
 // (channel, kx) pairs and the kx shift-sum is done in the epilogue through LDS, so the matrix core
 // runs at 27/32 row utilisation instead of 3/32.
 #include "vcg_common.hpp"
+#include <type_traits>
 
 namespace {
 
@@ -35,11 +36,11 @@ struct ConvParams {
     int ws_t, ws_m, ws_k;
 };
 
-template <int KH, int KW, int S, int CK>
+template <int KH, int KW, int S, int CK, int XT>
 struct ConvCfg {
     static constexpr int ROWS = 8;
     static constexpr int IH = (ROWS - 1) * S + KH;
-    static constexpr int IW = 31 * S + KW;
+    static constexpr int IW = (32 * XT - 1) * S + KW;
     static constexpr int PLANE = IH * IW;
     static constexpr int T = KH * KW;
     static constexpr int IN_ELEMS = CK * PLANE;
@@ -49,9 +50,9 @@ struct ConvCfg {
     static constexpr size_t LDS_BYTES = (size_t)(IN_ELEMS + W_ELEMS) * sizeof(float);
 };
 
-template <int KH, int KW, int S, int CK>
-__global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvParams p) {
-    using C = ConvCfg<KH, KW, S, CK>;
+template <int KH, int KW, int S, int CK, int XT>
+__global__ __launch_bounds__(256, 2) void conv_fwd_kernel(const ConvParams p) {
+    using C = ConvCfg<KH, KW, S, CK, XT>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* s_in = smem;               // [CK][IH][IW]
     float* s_w = smem + C::IN_ELEMS;  // [CK][T][64]
@@ -63,37 +64,51 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvParams p) {
     const int tx = b % p.tiles_x;   b /= p.tiles_x;
     const int ty = b % p.tiles_y;   b /= p.tiles_y;
     const int n = b;
-    const int ox0 = tx * 32, oy0 = ty * C::ROWS, co0 = cb * 64;
+    const int ox0 = tx * 32 * XT, oy0 = ty * C::ROWS, co0 = cb * 64;
     const int gy0 = oy0 * S - p.pad_top, gx0 = ox0 * S - p.pad_left;
     const float* xn = p.x + (size_t)n * p.cin * p.h * p.w_;
 
     float rin[C::IN_PT], rw[C::W_PT];
 
+    // per-thread input offsets inside one image's [cin][h][w] block, computed once (-1 = zero padding);
+    // a chunk only adds a wave-uniform channel offset, so the staging loop costs ~2 VALU per element
+    int in_off[C::IN_PT];
+#pragma unroll
+    for (int i = 0; i < C::IN_PT; ++i) {
+        const int e = tid + i * 256;
+        int off = -1;
+        if (e < C::IN_ELEMS) {
+            const int ci = e / C::PLANE, rem = e % C::PLANE;
+            const int r = rem / C::IW, c = rem % C::IW;
+            const int gy = gy0 + r, gx = gx0 + c;
+            if (gy >= 0 && gy < p.h && gx >= 0 && gx < p.w_) off = (ci * p.h + gy) * p.w_ + gx;
+        }
+        in_off[i] = off;
+    }
+    const int hw = p.h * p.w_;
+    const int wvu = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave id, provably uniform
+    const bool m_ok = co0 + lane < p.cout;
+
     auto load_chunk = [&](int ci0) {
+        const float* xc = xn + (size_t)ci0 * hw;
+        const unsigned lim = (unsigned)((p.cin - ci0) * hw);    // channels >= cin read as zero
+        // every load is unconditional from a clamped (always valid) address and masked afterwards: a
+        // conditional load makes hipcc branch around it and drain vmcnt per element
 #pragma unroll
         for (int i = 0; i < C::IN_PT; ++i) {
-            const int e = tid + i * 256;
-            float v = 0.f;
-            if (e < C::IN_ELEMS) {
-                const int ci = e / C::PLANE, rem = e % C::PLANE;
-                const int r = rem / C::IW, c = rem % C::IW;
-                const int gy = gy0 + r, gx = gx0 + c, ch = ci0 + ci;
-                if (ch < p.cin && gy >= 0 && gy < p.h && gx >= 0 && gx < p.w_)
-                    v = xn[((size_t)ch * p.h + gy) * p.w_ + gx];
-            }
-            rin[i] = v;
+            const bool ok = (unsigned)in_off[i] < lim;
+            const float v = xc[ok ? in_off[i] : 0];
+            rin[i] = ok ? v : 0.f;
         }
+        // weights: element e = tid + 256 i  ->  (ci, tap) = wave-uniform, m = lane: scalar addressing
 #pragma unroll
         for (int i = 0; i < C::W_PT; ++i) {
-            const int e = tid + i * 256;
-            float v = 0.f;
-            if (e < C::W_ELEMS) {
-                const int m = e & 63, q = e >> 6;
-                const int t = q % C::T, ci = q / C::T;
-                const int ch = ci0 + ci, tap = p.flip ? (C::T - 1 - t) : t;
-                if (ch < p.cin && co0 + m < p.cout) v = p.w[((size_t)tap * p.cin + ch) * p.cout + co0 + m];
-            }
-            rw[i] = v;
+            const int q = wvu + 4 * i;
+            const int t = q % C::T, ci = q / C::T;
+            const int ch = ci0 + ci, tap = p.flip ? (C::T - 1 - t) : t;
+            const bool ok = ch < p.cin && m_ok;
+            const float v = p.w[ok ? (tap * p.cin + ch) * p.cout + co0 + lane : 0];
+            rw[i] = ok ? v : 0.f;
         }
     };
     auto store_chunk = [&]() {
@@ -109,13 +124,15 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvParams p) {
         }
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[2][2][XT];   // [co tile][row][x tile]
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int x = 0; x < XT; ++x)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][x][r] = 0.f;
 
     const float* bbase = s_in + half * C::PLANE + (wv * 2 * S) * C::IW + l31 * S;
     const float* abase = s_w + half * C::T * 64 + l31;
@@ -136,38 +153,70 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvParams p) {
                     const int t = ky * KW + kx;
                     const float a0 = abase[(cp * 2 * C::T + t) * 64];
                     const float a1 = abase[(cp * 2 * C::T + t) * 64 + 32];
-                    const float b0 = bbase[cp * 2 * C::PLANE + ky * C::IW + kx];
-                    const float b1 = bbase[cp * 2 * C::PLANE + (S + ky) * C::IW + kx];
-                    acc[0][0] = mfma32(a0, b0, acc[0][0]);
-                    acc[0][1] = mfma32(a0, b1, acc[0][1]);
-                    acc[1][0] = mfma32(a1, b0, acc[1][0]);
-                    acc[1][1] = mfma32(a1, b1, acc[1][1]);
+#pragma unroll
+                    for (int xt = 0; xt < XT; ++xt) {
+                        const float b0 = bbase[cp * 2 * C::PLANE + ky * C::IW + kx + xt * 32 * S];
+                        const float b1 = bbase[cp * 2 * C::PLANE + (S + ky) * C::IW + kx + xt * 32 * S];
+                        acc[0][0][xt] = mfma32(a0, b0, acc[0][0][xt]);
+                        acc[0][1][xt] = mfma32(a0, b1, acc[0][1][xt]);
+                        acc[1][0][xt] = mfma32(a1, b0, acc[1][0][xt]);
+                        acc[1][1][xt] = mfma32(a1, b1, acc[1][1][xt]);
+                    }
                 }
             }
         }
     }
 
-    // epilogue: y = act(acc + bias) + residual
+    // epilogue: y = act(acc + bias) + residual.  Interior tiles take a guard-free path.
     const int ox = ox0 + l31;
+    const bool full = (co0 + 64 <= p.cout) && (oy0 + C::ROWS <= p.oh) && (ox0 + 32 * XT <= p.ow);
+    const size_t plane = (size_t)p.oh * p.ow;
+    const size_t ob = ((size_t)n * p.cout + co0) * plane + (size_t)(oy0 + wv * 2) * p.ow + ox;
+    float* yb = p.y + ob;
+    const float* rb = p.residual ? p.residual + ob : nullptr;
+    // none / LeakyReLU / PReLU share one straight-line form  v >= 0 ? v : v*slope  (slope 1 = identity);
+    // tanh is only offered by the small-M kernel (the API rejects it here).
+    const float* bp = p.bias ? p.bias : vcg_zero_word;
+    const int bmask = p.bias ? ~0 : 0;
+    const bool is_prelu = p.act == VCG_ACT_PRELU;
+    const float* ap = is_prelu ? p.prelu : vcg_zero_word;
+    const int amask = is_prelu ? ~0 : 0;
+    const float slope_u = (p.act == VCG_ACT_LRELU) ? p.alpha : 1.f;
+    auto emit = [&](auto guard_tag, auto res_tag) {
+        constexpr bool GUARD = decltype(guard_tag)::value, RES = decltype(res_tag)::value;
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
+        for (int mt = 0; mt < 2; ++mt) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int co = co0 + mt * 32 + mfma_row(r, lane);
-            if (co >= p.cout) continue;
-            const float bv = p.bias ? p.bias[co] : 0.f;
-            const float al = (p.act == VCG_ACT_PRELU) ? p.prelu[co] : p.alpha;
+            for (int r = 0; r < 16; ++r) {
+                const int row = mt * 32 + mfma_row(r, lane);
+                const int co = co0 + row;
+                const bool co_ok = !GUARD || co < p.cout;
+                const int cs = co_ok ? co : co0;
+                const float bv = bp[cs & bmask];
+                const float pa = ap[cs & amask];
+                const float al = is_prelu ? pa : slope_u;
 #pragma unroll
-            for (int rt = 0; rt < 2; ++rt) {
-                const int oy = oy0 + wv * 2 + rt;
-                if (oy < p.oh && ox < p.ow) {
-                    const size_t idx = (((size_t)n * p.cout + co) * p.oh + oy) * p.ow + ox;
-                    float v = apply_act(acc[mt][rt][r] + bv, p.act, al);
-                    if (p.residual) v += p.residual[idx];
-                    p.y[idx] = v;
+                for (int rt = 0; rt < 2; ++rt) {
+#pragma unroll
+                    for (int xt = 0; xt < XT; ++xt) {
+                        const size_t o = (size_t)row * plane + (size_t)rt * p.ow + xt * 32;
+                        if (!GUARD || (co_ok && oy0 + wv * 2 + rt < p.oh && ox + xt * 32 < p.ow)) {
+                            float v = acc[mt][rt][xt][r] + bv;
+                            v = v >= 0.f ? v : v * al;
+                            if (RES) v += rb[o];
+                            yb[o] = v;
+                        }
+                    }
                 }
             }
         }
+    };
+    using T_ = std::true_type;
+    using F_ = std::false_type;
+    if (full) {
+        if (rb) emit(F_{}, T_{}); else emit(F_{}, F_{});
+    } else {
+        if (rb) emit(T_{}, T_{}); else emit(T_{}, F_{});
     }
 }
 
@@ -211,19 +260,23 @@ __global__ __launch_bounds__(256) void conv_smallm_kernel(const ConvParams p) {
     const int mrows = p.cout * KW;
 
     float rin[C::IN_PT], rw[C::W_PT];
+    // the staged rows are exactly 64 floats wide: row (ci, r) is wave-uniform and the lane is the column,
+    // so the input addressing is scalar + lane
+    const int wvu = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int gx = gx0 + lane;
+    const bool col_ok = gx >= 0 && gx < p.w_;
+    const int gxc = min(max(gx, 0), p.w_ - 1);
+    const int hw = p.h * p.w_;
     auto load_chunk = [&](int ci0) {
 #pragma unroll
         for (int i = 0; i < C::IN_PT; ++i) {
-            const int e = tid + i * 256;
-            float v = 0.f;
-            if (e < C::IN_ELEMS) {
-                const int ci = e / C::PLANE, rem = e % C::PLANE;
-                const int r = rem / C::XW, c = rem % C::XW;
-                const int gy = gy0 + r, gx = gx0 + c, ch = ci0 + ci;
-                if (ch < p.cin && gy >= 0 && gy < p.h && gx >= 0 && gx < p.w_)
-                    v = xn[((size_t)ch * p.h + gy) * p.w_ + gx];
-            }
-            rin[i] = v;
+            const int q = wvu + 4 * i;                  // row index inside the chunk tile
+            const int r = q % C::IH, ci = q / C::IH;
+            const int gy = gy0 + r, ch = ci0 + ci;
+            const bool ok = col_ok && ch < p.cin && gy >= 0 && gy < p.h;
+            const int chc = min(ch, p.cin - 1), gyc = min(max(gy, 0), p.h - 1);      // scalar clamps
+            const float v = xn[(size_t)chc * hw + gyc * p.w_ + gxc];
+            rin[i] = ok ? v : 0.f;
         }
 #pragma unroll
         for (int i = 0; i < C::W_PT; ++i) {
@@ -233,12 +286,12 @@ __global__ __launch_bounds__(256) void conv_smallm_kernel(const ConvParams p) {
                 const int mi = e & 31, q = e >> 5;
                 const int ky = q % KH, ci = q / KH;
                 const int ch = ci0 + ci;
-                if (ch < p.cin && mi < mrows) {
-                    const int mch = mi / KW, kx = mi % KW;
-                    int tap = ky * KW + kx;
-                    if (p.flip) tap = KH * KW - 1 - tap;
-                    v = p.w[(size_t)tap * p.ws_t + (size_t)mch * p.ws_m + (size_t)ch * p.ws_k];
-                }
+                const bool ok = ch < p.cin && mi < mrows;
+                const int mch = mi / KW, kx = mi % KW;
+                int tap = ky * KW + kx;
+                if (p.flip) tap = KH * KW - 1 - tap;
+                const float wv_ = p.w[ok ? tap * p.ws_t + mch * p.ws_m + ch * p.ws_k : 0];
+                v = ok ? wv_ : 0.f;
             }
             rw[i] = v;
         }
@@ -331,15 +384,15 @@ int launch_with_lds(Kern kern, int grid, size_t lds, const ConvParams& p, hipStr
     return VCG_OK;
 }
 
-template <int KH, int KW, int S, int CK>
+template <int KH, int KW, int S, int CK, int XT>
 int launch_conv(ConvParams p, hipStream_t st) {
-    using C = ConvCfg<KH, KW, S, CK>;
-    p.tiles_x = ceil_div(p.ow, 32);
+    using C = ConvCfg<KH, KW, S, CK, XT>;
+    p.tiles_x = ceil_div(p.ow, 32 * XT);
     p.tiles_y = ceil_div(p.oh, C::ROWS);
     p.co_blocks = ceil_div(p.cout, 64);
     const long grid = (long)p.tiles_x * p.tiles_y * p.co_blocks * p.n;
     if (grid <= 0 || grid > 0x7fffffffL) return VCG_E_SHAPE;
-    return launch_with_lds(conv_fwd_kernel<KH, KW, S, CK>, (int)grid, C::LDS_BYTES, p, st);
+    return launch_with_lds(conv_fwd_kernel<KH, KW, S, CK, XT>, (int)grid, C::LDS_BYTES, p, st);
 }
 
 template <int KH, int KW, int CK>
@@ -380,12 +433,16 @@ int vcg_internal_conv(const float* x, const float* w, float* y, int n, int cin, 
         if (kh == 5 && kw == 5) return launch_smallm<5, 5, 8>(p, st);
         return VCG_E_UNSUPPORTED;
     }
-    if (kh == 3 && kw == 3 && stride == 1) return launch_conv<3, 3, 1, 8>(p, st);
-    if (kh == 3 && kw == 3 && stride == 2) return launch_conv<3, 3, 2, 8>(p, st);
-    if (kh == 4 && kw == 4 && stride == 1) return launch_conv<4, 4, 1, 8>(p, st);
-    if (kh == 4 && kw == 4 && stride == 2) return launch_conv<4, 4, 2, 4>(p, st);
-    if (kh == 5 && kw == 5 && stride == 1) return launch_conv<5, 5, 1, 8>(p, st);
-    if (kh == 5 && kw == 5 && stride == 2) return launch_conv<5, 5, 2, 4>(p, st);
-    if (kh == 9 && kw == 9 && stride == 1) return launch_conv<9, 9, 1, 4>(p, st);
+    if (p.act == VCG_ACT_TANH) return VCG_E_UNSUPPORTED;   // tanh epilogue: small-M kernel only (<= 32/kw channels)
+    // wide outputs use 64-column tiles (two MFMA x-tiles per wave: half the barriers and weight staging per
+    // MFMA, and 1024 workgroups = 2 full rounds of 2 per CU at the C2 trunk shape instead of 2.67 rounds of 3)
+    const bool wide = ow > 32;
+    if (kh == 3 && kw == 3 && stride == 1) return wide ? launch_conv<3, 3, 1, 8, 2>(p, st) : launch_conv<3, 3, 1, 8, 1>(p, st);
+    if (kh == 3 && kw == 3 && stride == 2) return launch_conv<3, 3, 2, 8, 1>(p, st);
+    if (kh == 4 && kw == 4 && stride == 1) return launch_conv<4, 4, 1, 8, 1>(p, st);   // XT=2 spills here (measured slower)
+    if (kh == 4 && kw == 4 && stride == 2) return launch_conv<4, 4, 2, 4, 1>(p, st);
+    if (kh == 5 && kw == 5 && stride == 1) return wide ? launch_conv<5, 5, 1, 8, 2>(p, st) : launch_conv<5, 5, 1, 8, 1>(p, st);
+    if (kh == 5 && kw == 5 && stride == 2) return launch_conv<5, 5, 2, 4, 1>(p, st);
+    if (kh == 9 && kw == 9 && stride == 1) return launch_conv<9, 9, 1, 4, 1>(p, st);
     return VCG_E_UNSUPPORTED;
 }

@@ -11,6 +11,7 @@
 // Serves: Conv2DTranspose forward (model.py:72 via :288) and stride-2 Conv2D dgrad (D blocks 2-9,
 // model.py:843-871; PatchGAN k4 s2).
 #include "vcg_common.hpp"
+#include <type_traits>
 
 namespace {
 
@@ -68,31 +69,40 @@ __global__ __launch_bounds__(256) void convt_kernel(const ConvTParams p) {
     const float* xn = p.x + (size_t)n * p.cin * p.h * p.w_;
 
     float rin[C::IN_PT], rw[C::W_PT];
+    int in_off[C::IN_PT];   // offsets inside one image, computed once (-1 = zero padding)
+#pragma unroll
+    for (int i = 0; i < C::IN_PT; ++i) {
+        const int e = tid + i * 256;
+        int off = -1;
+        if (e < C::IN_ELEMS) {
+            const int ci = e / C::PLANE, rem = e % C::PLANE;
+            const int r = rem / C::NC, c = rem % C::NC;
+            const int gy = gy0 + r, gx = gx0 + c;
+            if (gy >= 0 && gy < p.h && gx >= 0 && gx < p.w_) off = (ci * p.h + gy) * p.w_ + gx;
+        }
+        in_off[i] = off;
+    }
+    const int hw = p.h * p.w_;
+    const int wvu = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool m_ok = co0 + lane < p.cout;
     auto load_chunk = [&](int ci0) {
+        const float* xc = xn + (size_t)ci0 * hw;
+        const unsigned lim = (unsigned)((p.cin - ci0) * hw);
+        // unconditional loads from clamped addresses, masked afterwards (no per-element branches)
 #pragma unroll
         for (int i = 0; i < C::IN_PT; ++i) {
-            const int e = tid + i * 256;
-            float v = 0.f;
-            if (e < C::IN_ELEMS) {
-                const int ci = e / C::PLANE, rem = e % C::PLANE;
-                const int r = rem / C::NC, c = rem % C::NC;
-                const int gy = gy0 + r, gx = gx0 + c, ch = ci0 + ci;
-                if (ch < p.cin && gy >= 0 && gy < p.h && gx >= 0 && gx < p.w_)
-                    v = xn[((size_t)ch * p.h + gy) * p.w_ + gx];
-            }
-            rin[i] = v;
+            const bool ok = (unsigned)in_off[i] < lim;
+            const float v = xc[ok ? in_off[i] : 0];
+            rin[i] = ok ? v : 0.f;
         }
 #pragma unroll
         for (int i = 0; i < C::W_PT; ++i) {
-            const int e = tid + i * 256;
-            float v = 0.f;
-            if (e < C::W_ELEMS) {
-                const int m = e & 63, q = e >> 6;
-                const int t = q % C::T, ci = q / C::T;
-                const int ch = ci0 + ci;
-                if (ch < p.cin && co0 + m < p.cout) v = p.w[((size_t)t * p.cin + ch) * p.cout + co0 + m];
-            }
-            rw[i] = v;
+            const int q = wvu + 4 * i;
+            const int t = q % C::T, ci = q / C::T;
+            const int ch = ci0 + ci;
+            const bool ok = ch < p.cin && m_ok;
+            const float v = p.w[ok ? (t * p.cin + ch) * p.cout + co0 + lane : 0];
+            rw[i] = ok ? v : 0.f;
         }
     };
     auto store_chunk = [&]() {
@@ -155,39 +165,67 @@ __global__ __launch_bounds__(256) void convt_kernel(const ConvTParams p) {
         }
     }
 
+    // epilogue: the two x-phases of a lane form one float2.  Interior tiles of even-width outputs take a
+    // guard-free path; none / LeakyReLU / PReLU share  v >= 0 ? v : v*slope  (slope 1 = identity).
     const int qy = qy0 + wv, qx = qx0 + l31;
     const bool vec_ok = (p.ow % 2) == 0;
+    const bool full = vec_ok && (co0 + 64 <= p.cout) && (2 * (qy0 + C::QROWS) <= p.oh) && (2 * (qx0 + 32) <= p.ow);
+    const size_t plane = (size_t)p.oh * p.ow;
+    const size_t ob = ((size_t)n * p.cout + co0) * plane + (size_t)(2 * qy) * p.ow + 2 * qx;
+    const float* bp = p.bias ? p.bias : vcg_zero_word;
+    const int bmask = p.bias ? ~0 : 0;
+    const bool is_prelu = p.act == VCG_ACT_PRELU;
+    const float* ap = is_prelu ? p.prelu : vcg_zero_word;
+    const int amask = is_prelu ? ~0 : 0;
+    const float slope_u = (p.act == VCG_ACT_LRELU) ? p.alpha : 1.f;
+    auto emit = [&](auto guard_tag, auto res_tag) {
+        constexpr bool GUARD = decltype(guard_tag)::value, RES = decltype(res_tag)::value;
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
+        for (int mt = 0; mt < 2; ++mt) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int co = co0 + mt * 32 + mfma_row(r, lane);
-            if (co >= p.cout) continue;
-            const float bvv = p.bias ? p.bias[co] : 0.f;
-            const float al = (p.act == VCG_ACT_PRELU) ? p.prelu[co] : p.alpha;
+            for (int r = 0; r < 16; ++r) {
+                const int row = mt * 32 + mfma_row(r, lane);
+                const int co = co0 + row;
+                const bool co_ok = !GUARD || co < p.cout;
+                const int cs = co_ok ? co : co0;
+                const float bvv = bp[cs & bmask];
+                const float pa = ap[cs & amask];
+                const float al = is_prelu ? pa : slope_u;
 #pragma unroll
-            for (int py = 0; py < 2; ++py) {
-                const int oy = 2 * qy + py, ox = 2 * qx;
-                if (oy >= p.oh || ox >= p.ow) continue;
-                const size_t idx = (((size_t)n * p.cout + co) * p.oh + oy) * p.ow + ox;
-                float v0 = apply_act(acc[py][0][mt][r] + bvv, p.act, al);
-                float v1 = apply_act(acc[py][1][mt][r] + bvv, p.act, al);
-                if (vec_ok) {
-                    if (p.residual) {
-                        const float2 rr = *reinterpret_cast<const float2*>(p.residual + idx);
-                        v0 += rr.x; v1 += rr.y;
-                    }
-                    *reinterpret_cast<float2*>(p.y + idx) = make_float2(v0, v1);
-                } else {
-                    if (p.residual) v0 += p.residual[idx];
-                    p.y[idx] = v0;
-                    if (ox + 1 < p.ow) {
-                        if (p.residual) v1 += p.residual[idx + 1];
-                        p.y[idx + 1] = v1;
+                for (int py = 0; py < 2; ++py) {
+                    const size_t o = ob + (size_t)row * plane + (size_t)py * p.ow;
+                    float v0 = acc[py][0][mt][r] + bvv, v1 = acc[py][1][mt][r] + bvv;
+                    v0 = v0 >= 0.f ? v0 : v0 * al;
+                    v1 = v1 >= 0.f ? v1 : v1 * al;
+                    if (!GUARD) {
+                        if (RES) { const float2 rr = *reinterpret_cast<const float2*>(p.residual + o); v0 += rr.x; v1 += rr.y; }
+                        *reinterpret_cast<float2*>(p.y + o) = make_float2(v0, v1);
+                    } else {
+                        const int oy = 2 * qy + py, ox = 2 * qx;
+                        if (co_ok && oy < p.oh && ox < p.ow) {
+                            if (vec_ok) {
+                                if (RES) { const float2 rr = *reinterpret_cast<const float2*>(p.residual + o); v0 += rr.x; v1 += rr.y; }
+                                *reinterpret_cast<float2*>(p.y + o) = make_float2(v0, v1);
+                            } else {
+                                if (RES) v0 += p.residual[o];
+                                p.y[o] = v0;
+                                if (ox + 1 < p.ow) {
+                                    if (RES) v1 += p.residual[o + 1];
+                                    p.y[o + 1] = v1;
+                                }
+                            }
+                        }
                     }
                 }
             }
         }
+    };
+    using T_ = std::true_type;
+    using F_ = std::false_type;
+    if (full) {
+        if (p.residual) emit(F_{}, T_{}); else emit(F_{}, F_{});
+    } else {
+        if (p.residual) emit(T_{}, T_{}); else emit(T_{}, F_{});
     }
 }
 
@@ -223,11 +261,12 @@ int vcg_internal_convt(const float* x, const float* w, float* y, int n, int cin,
     p.act = ep ? ep->act : VCG_ACT_NONE;
     p.alpha = ep ? ep->act_alpha : 0.f;
     if (p.act == VCG_ACT_PRELU && p.prelu == nullptr) return VCG_E_NULL;
+    if (p.act == VCG_ACT_TANH) return VCG_E_UNSUPPORTED;
     p.n = n; p.cin = cin; p.h = h; p.w_ = wd; p.cout = cout; p.oh = oh; p.ow = ow;
     if (n <= 0 || cin <= 0 || cout <= 0 || oh <= 0 || ow <= 0) return VCG_E_SHAPE;
 #define VCG_CT(K_, A_, B_, CK_) if (k == K_ && cby == A_ && cbx == B_) return launch_convt<K_, A_, B_, CK_>(p, st)
-    VCG_CT(3, 0, 0, 8); VCG_CT(3, 0, 1, 8); VCG_CT(3, 1, 0, 8); VCG_CT(3, 1, 1, 8);
-    VCG_CT(4, 1, 1, 8);
+    VCG_CT(3, 0, 0, 16); VCG_CT(3, 0, 1, 16); VCG_CT(3, 1, 0, 16); VCG_CT(3, 1, 1, 16);
+    VCG_CT(4, 1, 1, 16);
     VCG_CT(5, 1, 1, 8); VCG_CT(5, 1, 2, 8); VCG_CT(5, 2, 1, 8); VCG_CT(5, 2, 2, 8);
 #undef VCG_CT
     return VCG_E_UNSUPPORTED;
