@@ -203,13 +203,14 @@ def test_train_step_parity(rt, wiring, losses, disc, k):
     shows that).  Primed, the update is smooth in the gradient and parity is meaningful at 1e-3."""
     bs = 4
     G, D, df, models, opt, mk = _build_pair(rt, wiring, losses, disc, k, ADAM_V0)
-    orc = mk(torch.float64)
+    orc, orc32 = mk(torch.float64), mk(torch.float32)
     g0, d0 = G.get_weights_dict(), D.get_weights_dict()
     tag = "%s/%s/%s/k%d" % (wiring, losses, disc, k)
     for it in range(2):
         lr, hr = _frames(10 + it, bs, 64, 64), _frames(20 + it, bs, 128, 128)
         got = _loop_body(wiring, models, lr, hr, bs)
         ref = orc.train_step(torch.tensor(lr, dtype=torch.float64), torch.tensor(hr, dtype=torch.float64))
+        orc32.train_step(torch.tensor(lr), torch.tensor(hr))
         scale = max(abs(v) for v in ref) + 1e-6
         for name, a, b in zip(("disc", "gan", "content", "adv"), got, ref):
             err = abs(a - b) / scale
@@ -223,23 +224,26 @@ def test_train_step_parity(rt, wiring, losses, disc, k):
     e_d = rel_err(torch.tensor(D.predict(hr0)), d_ref)
     report("train_step %s after: G.predict err=%.2e  D.predict err=%.2e" % (tag, e_g, e_d))
     assert e_g < TOL and e_d < TOL
-    # every weight: the UPDATE (after - before) against the oracle's update, relative to the largest update
-    # of that model; BN moving statistics relative to their own scale
+    # every weight: the UPDATE (after - before) against the fp64 oracle's update, relative to the largest
+    # update of that model.  Gradients such as dgamma = sum(dz * xhat) cancel heavily and carry activation
+    # masks, so their fp32 error is percent-level in ANY fp32 implementation: the fp32 run of the oracle
+    # sets the scale (bound: 5e-3, or 4x the fp32 oracle's own error for that tensor).
     worst_stat = 0.0
-    for model, ow, w0, mtag in ((G, orc.g_w, g0, "G"), (D, orc.d_w, d0, "D")):
+    for model, ow, ow32, w0, mtag in ((G, orc.g_w, orc32.g_w, g0, "G"), (D, orc.d_w, orc32.d_w, d0, "D")):
         got_w = model.get_weights_dict()
         upd_scale = max(float(np.max(np.abs(refv.detach().numpy() - w0[name]))) for name, refv in ow.items()
                         if not name.endswith(("/moving_mean", "/moving_variance")))
-        worst = 0.0
+        worst, worst32 = 0.0, 0.0
         for name, refv in ow.items():
             a, b = got_w[name].astype(np.float64), refv.detach().numpy()
             if name.endswith(("/moving_mean", "/moving_variance")):
                 worst_stat = max(worst_stat, float(np.max(np.abs(a - b)) / (np.max(np.abs(b)) + 1e-12)))
                 continue
-            e = float(np.max(np.abs((a - w0[name]) - (b - w0[name]))) / upd_scale)
-            worst = max(worst, e)
-            assert e < 5e-3, (mtag, name, e)
-        report("train_step %s after: %s max update=%.2e worst update err=%.2e" % (tag, mtag, upd_scale, worst))
+            e = float(np.max(np.abs(a - b)) / upd_scale)
+            e32 = float(np.max(np.abs(ow32[name].detach().double().numpy() - b)) / upd_scale)
+            worst, worst32 = max(worst, e), max(worst32, e32)
+            assert e < max(5e-3, 4 * e32), (mtag, name, e, e32)
+        report("train_step %s after: %s max update=%.2e worst update err=%.2e (oracle-fp32 %.2e)" % (tag, mtag, upd_scale, worst, worst32))
     report("train_step %s after: moving-stat err=%.2e" % (tag, worst_stat))
     assert worst_stat < TOL
 

@@ -51,7 +51,7 @@ struct ConvCfg {
 };
 
 template <int KH, int KW, int S, int CK, int XT>
-__global__ __launch_bounds__(256, 2) void conv_fwd_kernel(const ConvParams p) {
+__global__ __launch_bounds__(256, (KH >= 9 ? 1 : 2)) void conv_fwd_kernel(const ConvParams p) {
     using C = ConvCfg<KH, KW, S, CK, XT>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* s_in = smem;               // [CK][IH][IW]
@@ -86,7 +86,6 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(const ConvParams p) {
         in_off[i] = off;
     }
     const int hw = p.h * p.w_;
-    const int wvu = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave id, provably uniform
     const bool m_ok = co0 + lane < p.cout;
 
     auto load_chunk = [&](int ci0) {
@@ -100,10 +99,10 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(const ConvParams p) {
             const float v = xc[ok ? in_off[i] : 0];
             rin[i] = ok ? v : 0.f;
         }
-        // weights: element e = tid + 256 i  ->  (ci, tap) = wave-uniform, m = lane: scalar addressing
+        // weights: element e = tid + 256 i  ->  row q = (ci, tap), m = lane
 #pragma unroll
         for (int i = 0; i < C::W_PT; ++i) {
-            const int q = wvu + 4 * i;
+            const int q = wv + 4 * i;
             const int t = q % C::T, ci = q / C::T;
             const int ch = ci0 + ci, tap = p.flip ? (C::T - 1 - t) : t;
             const bool ok = ch < p.cin && m_ok;
@@ -143,7 +142,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(const ConvParams p) {
         __syncthreads();
         store_chunk();
         __syncthreads();
-        if (c + 1 < nchunks) load_chunk((c + 1) * CK);
+        if (c + 1 < nchunks) load_chunk((c + 1) * CK);   // in flight during this chunk's MFMAs
 #pragma unroll
         for (int cp = 0; cp < CK / 2; ++cp) {
 #pragma unroll
@@ -170,10 +169,12 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(const ConvParams p) {
     // epilogue: y = act(acc + bias) + residual.  Interior tiles take a guard-free path.
     const int ox = ox0 + l31;
     const bool full = (co0 + 64 <= p.cout) && (oy0 + C::ROWS <= p.oh) && (ox0 + 32 * XT <= p.ow);
-    const size_t plane = (size_t)p.oh * p.ow;
-    const size_t ob = ((size_t)n * p.cout + co0) * plane + (size_t)(oy0 + wv * 2) * p.ow + ox;
-    float* yb = p.y + ob;
-    const float* rb = p.residual ? p.residual + ob : nullptr;
+    // 32-bit element offsets inside this image's [cout][oh][ow] block: one scalar base + a vector offset
+    const int plane = p.oh * p.ow;
+    const size_t img = (size_t)n * p.cout * plane;
+    float* yb = p.y + img;
+    const float* rb = p.residual ? p.residual + img : nullptr;
+    const int ob = (co0 + 4 * half) * plane + (oy0 + wv * 2) * p.ow + ox;
     // none / LeakyReLU / PReLU share one straight-line form  v >= 0 ? v : v*slope  (slope 1 = identity);
     // tanh is only offered by the small-M kernel (the API rejects it here).
     const float* bp = p.bias ? p.bias : vcg_zero_word;
@@ -199,7 +200,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(const ConvParams p) {
                 for (int rt = 0; rt < 2; ++rt) {
 #pragma unroll
                     for (int xt = 0; xt < XT; ++xt) {
-                        const size_t o = (size_t)row * plane + (size_t)rt * p.ow + xt * 32;
+                        const int o = ob + (row - 4 * half) * plane + rt * p.ow + xt * 32;
                         if (!GUARD || (co_ok && oy0 + wv * 2 + rt < p.oh && ox + xt * 32 < p.ow)) {
                             float v = acc[mt][rt][xt][r] + bv;
                             v = v >= 0.f ? v : v * al;
@@ -441,7 +442,7 @@ int vcg_internal_conv(const float* x, const float* w, float* y, int n, int cin, 
     if (kh == 3 && kw == 3 && stride == 2) return launch_conv<3, 3, 2, 8, 1>(p, st);
     if (kh == 4 && kw == 4 && stride == 1) return launch_conv<4, 4, 1, 8, 1>(p, st);   // XT=2 spills here (measured slower)
     if (kh == 4 && kw == 4 && stride == 2) return launch_conv<4, 4, 2, 4, 1>(p, st);
-    if (kh == 5 && kw == 5 && stride == 1) return wide ? launch_conv<5, 5, 1, 8, 2>(p, st) : launch_conv<5, 5, 1, 8, 1>(p, st);
+    if (kh == 5 && kw == 5 && stride == 1) return launch_conv<5, 5, 1, 8, 1>(p, st);   // XT=2 spills (50 weight prefetch registers)
     if (kh == 5 && kw == 5 && stride == 2) return launch_conv<5, 5, 2, 4, 1>(p, st);
     if (kh == 9 && kw == 9 && stride == 1) return launch_conv<9, 9, 1, 4, 1>(p, st);
     return VCG_E_UNSUPPORTED;

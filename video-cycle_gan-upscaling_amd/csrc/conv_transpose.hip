@@ -83,7 +83,6 @@ __global__ __launch_bounds__(256) void convt_kernel(const ConvTParams p) {
         in_off[i] = off;
     }
     const int hw = p.h * p.w_;
-    const int wvu = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool m_ok = co0 + lane < p.cout;
     auto load_chunk = [&](int ci0) {
         const float* xc = xn + (size_t)ci0 * hw;
@@ -97,7 +96,7 @@ __global__ __launch_bounds__(256) void convt_kernel(const ConvTParams p) {
         }
 #pragma unroll
         for (int i = 0; i < C::W_PT; ++i) {
-            const int q = wvu + 4 * i;
+            const int q = wv + 4 * i;
             const int t = q % C::T, ci = q / C::T;
             const int ch = ci0 + ci;
             const bool ok = ch < p.cin && m_ok;
@@ -148,18 +147,23 @@ __global__ __launch_bounds__(256) void convt_kernel(const ConvTParams p) {
                 for (int ix = 0; ix < C::NDX; ++ix)
                     bv[iy][ix] = bbase[cp * 2 * C::PLANE + (C::DMAXY - (C::DMINY + iy)) * C::NC +
                                        (C::DMAXX - (C::DMINX + ix))];
+            // all A operands of this channel pair first (one batch of LDS reads), then the MFMAs: the
+            // compiler overlaps the next pair's reads with this pair's 2*T MFMAs
+            float av[C::T][2];
+#pragma unroll
+            for (int t = 0; t < C::T; ++t) {
+                av[t][0] = abase[(cp * 2 * C::T + t) * 64];
+                av[t][1] = abase[(cp * 2 * C::T + t) * 64 + 32];
+            }
 #pragma unroll
             for (int ky = 0; ky < K; ++ky) {
 #pragma unroll
                 for (int kx = 0; kx < K; ++kx) {
-                    constexpr int dummy = 0; (void)dummy;
                     const int t = ky * K + kx;
                     const int py = phase_of(ky, CBY), px = phase_of(kx, CBX);
                     const int iy = d_of(ky, CBY) - C::DMINY, ix = d_of(kx, CBX) - C::DMINX;
-                    const float a0 = abase[(cp * 2 * C::T + t) * 64];
-                    const float a1 = abase[(cp * 2 * C::T + t) * 64 + 32];
-                    acc[py][px][0] = mfma32(a0, bv[iy][ix], acc[py][px][0]);
-                    acc[py][px][1] = mfma32(a1, bv[iy][ix], acc[py][px][1]);
+                    acc[py][px][0] = mfma32(av[t][0], bv[iy][ix], acc[py][px][0]);
+                    acc[py][px][1] = mfma32(av[t][1], bv[iy][ix], acc[py][px][1]);
                 }
             }
         }
@@ -170,8 +174,11 @@ __global__ __launch_bounds__(256) void convt_kernel(const ConvTParams p) {
     const int qy = qy0 + wv, qx = qx0 + l31;
     const bool vec_ok = (p.ow % 2) == 0;
     const bool full = vec_ok && (co0 + 64 <= p.cout) && (2 * (qy0 + C::QROWS) <= p.oh) && (2 * (qx0 + 32) <= p.ow);
-    const size_t plane = (size_t)p.oh * p.ow;
-    const size_t ob = ((size_t)n * p.cout + co0) * plane + (size_t)(2 * qy) * p.ow + 2 * qx;
+    const int plane = p.oh * p.ow;
+    const size_t img = (size_t)n * p.cout * plane;
+    float* yimg = p.y + img;
+    const float* rimg = p.residual ? p.residual + img : nullptr;
+    const int ob = (co0 + 4 * half) * plane + (2 * qy) * p.ow + 2 * qx;
     const float* bp = p.bias ? p.bias : vcg_zero_word;
     const int bmask = p.bias ? ~0 : 0;
     const bool is_prelu = p.act == VCG_ACT_PRELU;
@@ -193,25 +200,25 @@ __global__ __launch_bounds__(256) void convt_kernel(const ConvTParams p) {
                 const float al = is_prelu ? pa : slope_u;
 #pragma unroll
                 for (int py = 0; py < 2; ++py) {
-                    const size_t o = ob + (size_t)row * plane + (size_t)py * p.ow;
+                    const int o = ob + (row - 4 * half) * plane + py * p.ow;
                     float v0 = acc[py][0][mt][r] + bvv, v1 = acc[py][1][mt][r] + bvv;
                     v0 = v0 >= 0.f ? v0 : v0 * al;
                     v1 = v1 >= 0.f ? v1 : v1 * al;
                     if (!GUARD) {
-                        if (RES) { const float2 rr = *reinterpret_cast<const float2*>(p.residual + o); v0 += rr.x; v1 += rr.y; }
-                        *reinterpret_cast<float2*>(p.y + o) = make_float2(v0, v1);
+                        if (RES) { const float2 rr = *reinterpret_cast<const float2*>(rimg + o); v0 += rr.x; v1 += rr.y; }
+                        *reinterpret_cast<float2*>(yimg + o) = make_float2(v0, v1);
                     } else {
                         const int oy = 2 * qy + py, ox = 2 * qx;
                         if (co_ok && oy < p.oh && ox < p.ow) {
                             if (vec_ok) {
-                                if (RES) { const float2 rr = *reinterpret_cast<const float2*>(p.residual + o); v0 += rr.x; v1 += rr.y; }
-                                *reinterpret_cast<float2*>(p.y + o) = make_float2(v0, v1);
+                                if (RES) { const float2 rr = *reinterpret_cast<const float2*>(rimg + o); v0 += rr.x; v1 += rr.y; }
+                                *reinterpret_cast<float2*>(yimg + o) = make_float2(v0, v1);
                             } else {
-                                if (RES) v0 += p.residual[o];
-                                p.y[o] = v0;
+                                if (RES) v0 += rimg[o];
+                                yimg[o] = v0;
                                 if (ox + 1 < p.ow) {
-                                    if (RES) v1 += p.residual[o + 1];
-                                    p.y[o + 1] = v1;
+                                    if (RES) v1 += rimg[o + 1];
+                                    yimg[o + 1] = v1;
                                 }
                             }
                         }

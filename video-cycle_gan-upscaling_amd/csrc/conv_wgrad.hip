@@ -42,11 +42,11 @@ struct WgCfg {
     static constexpr int AST = TH * 32 + 1;             // odd stride between m rows of the A tile
     static constexpr int BH = (TH - 1) * S + K;
     static constexpr int BW = 31 * S + K;
-    // conflict-free gather for 3x3 stride 1: row stride = 3, plane stride = 9 (mod 32) -> the 32 lanes
-    // of a j-tile (consecutive (jc,ky,kx)) hit 32 different banks
-    static constexpr int BRS = (K == 3 && S == 1) ? 35 : (BW | 1);
-    static constexpr int BPS0 = BH * BRS;
-    static constexpr int BPS = (K == 3 && S == 1) ? (((BPS0 + 31) / 32) * 32 + 9) : (BPS0 | 1);
+    // conflict-free gather: row stride = K and plane stride = K*K (mod 32) put element (jc,ky,kx) of a lane on
+    // bank (T*jc + K*ky + kx) mod 32 = j mod 32, i.e. the 32 lanes of a j-tile hit 32 different banks
+    static constexpr int round_to(int v, int r) { return v + ((r - v % 32) % 32 + 32) % 32; }
+    static constexpr int BRS = round_to(BW, K % 32);
+    static constexpr int BPS = round_to(BH * BRS, (K * K) % 32);
     static constexpr int A_ELEMS = 64 * TH * 32;
     static constexpr int B_ELEMS = JCMAX * BH * BW;
     static constexpr int A_PT = A_ELEMS / 256;
