@@ -120,10 +120,11 @@ int vcg_norm_act_bwd(const float* x, const float* dy, int n, int c, int hw, int 
 
 /* ---- plain activations: PReLU after 'initial/conv' (model.py:276), LeakyReLU (:73), tanh (:291) */
 /* dx = dy * act'(.) where the derivative is evaluated from the saved OUTPUT y (tanh, lrelu) or the
- * saved INPUT x (prelu).  dprelu_alpha[c] (optional) accumulates sum dy*min(x,0). */
+ * saved INPUT x (prelu).  dprelu_alpha[c] (optional) = sum dy*min(x,0); dsum[c] (optional) = sum dx over
+ * (n,hw) -- the bias gradient of the convolution in front, produced in the same pass. */
 size_t vcg_act_bwd_workspace_bytes(int n, int c, int hw);
 int vcg_act_bwd(const float* saved, const float* dy, int n, int c, int hw, int act, float act_alpha,
-                const float* prelu_alpha, float* dx, float* dprelu_alpha, void* ws, size_t ws_bytes,
+                const float* prelu_alpha, float* dx, float* dprelu_alpha, float* dsum, void* ws, size_t ws_bytes,
                 vcg_stream_t stream);
 /* out[c] = sum over n,hw of x */
 size_t vcg_channel_sum_workspace_bytes(int n, int c, int hw);
@@ -155,6 +156,11 @@ int vcg_axpby(const float* x, float* y, size_t count, float a, float b, vcg_stre
  * by the caller; p -= lr_t * m / (sqrt(v) + eps) */
 int vcg_adam_keras_multi(float* p, const float* g, float* m, float* v, size_t count, float lr_t,
                          float beta_1, float beta_2, float eps, vcg_stream_t stream);
+
+/* same update with the iteration count kept on the device: uses t = *t_dev + 1 for the bias correction and
+ * then increments *t_dev, so a hipGraph that captured the call replays correctly step after step */
+int vcg_adam_keras_multi_dev(float* p, const float* g, float* m, float* v, size_t count, float lr,
+                             float beta_1, float beta_2, float eps, int* t_dev, vcg_stream_t stream);
 
 /* ---- frame edge: upscaling/upscaler/data.py:253-270 ------------------------------------------- */
 /* uint8 NHWC -> fp32 NCHW, v/127.5 - 1 */

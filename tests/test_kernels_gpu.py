@@ -240,6 +240,13 @@ def test_adam_losses_layout(rt):
     lr_t = 1e-3 * math.sqrt(1 - 0.999 ** 3) / (1 - 0.9 ** 3)
     L.check(lib.vcg_adam_keras_multi(pd.data_ptr(), gd.data_ptr(), md.data_ptr(), vd.data_ptr(), n, lr_t, 0.9, 0.999, 1e-7, rt.stream), "adam")
     assert max(rel_err(pd, pr), rel_err(md, mr), rel_err(vd, vr)) < 1e-5
+    # graph-replayable variant: step count on the device (t = *t_dev + 1), counter incremented by the call
+    pd2, gd2, md2, vd2 = (t.float().to(rt.device) for t in (p, gr, m, v))
+    t_dev = torch.tensor([2], dtype=torch.int32, device=rt.device)
+    L.check(lib.vcg_adam_keras_multi_dev(pd2.data_ptr(), gd2.data_ptr(), md2.data_ptr(), vd2.data_ptr(), n, 1e-3, 0.9, 0.999, 1e-7,
+                                         t_dev.data_ptr(), rt.stream), "adam_dev")
+    assert int(t_dev.item()) == 3
+    assert max(rel_err(pd2, pr), rel_err(md2, mr), rel_err(vd2, vr)) < 1e-5
     # pixel loss
     a, b = torch.randn(2, 3, 17, 19, generator=g, dtype=torch.float64), torch.randn(2, 3, 17, 19, generator=g, dtype=torch.float64)
     for kind, code in (("mse", L.LOSS_MSE), ("mae", L.LOSS_MAE)):

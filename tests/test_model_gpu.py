@@ -312,3 +312,38 @@ def test_generator_gradients_direct(rt):
         # max-norm error of a gradient is set by a handful of such elements in ANY fp32 implementation
         assert err < max(TOL, 4 * e32), (k, err, e32)
     assert abs(val.item() - loss.item()) / loss.item() < 1e-4
+
+
+def test_graph_replay_matches_eager(rt):
+    """hipGraph capture of the loop body: replays must reproduce the eager three-call step bit for bit
+    (same kernels, same order, deterministic reductions), including the device-side Adam step counter."""
+    from upscaler import _engine as E
+    bs = 2
+    frames = [(_frames(30 + i, bs, 64, 64), _frames(40 + i, bs, 128, 128)) for i in range(4)]
+
+    def run(graph):
+        G, D, df, models, opt, mk = _build_pair(rt, "gan2", "wass", "patch", 3, 0.0)
+        tr = models[2].trainer
+        dev = [(E.to_device_nchw(rt, a), E.to_device_nchw(rt, b)) for a, b in frames]
+        out = []
+        if graph:
+            tr.capture_train_step(*dev[0])            # performs one real (eager) step on dev[0], then records
+            for a, b in dev[1:]:
+                out.append(tr.train_step_graph(a, b))
+        else:
+            # same Adam kernel as the graph path (step count on the device, lr_t evaluated in fp32 there)
+            tr._t_dev = torch.tensor([opt.iterations], dtype=torch.int32, device=rt.device)
+            tr.train_step(*dev[0])
+            for a, b in dev[1:]:
+                out.append(tr.train_step(a, b))
+        return out, G.get_weights_dict(), D.get_weights_dict(), opt.iterations
+
+    oe, ge, de, ie = run(False)
+    og, gg, dg, ig = run(True)
+    assert ie == ig == 8
+    report("graph replay losses %s vs eager %s" % (og[-1], oe[-1]))
+    for a, b in zip(oe, og):
+        assert a == b, (a, b)                       # identical kernels in identical order: bit for bit
+    for we, wg in ((ge, gg), (de, dg)):
+        for k in we:
+            assert np.array_equal(we[k], wg[k]), k

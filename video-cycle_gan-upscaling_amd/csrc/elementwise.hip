@@ -13,28 +13,51 @@ inline int pick_split_cs(int c, size_t per_channel) {
     return s;
 }
 
-// ---- activation backward (+ optional PReLU slope gradient partials) ---------------------------------
+// ---- activation backward (+ optional PReLU slope gradient and per-channel sum(dx) partials) -----------
+__device__ __forceinline__ float act_bwd_one(float s, float d, int act, float al, float& dal) {
+    float g;
+    if (act == VCG_ACT_TANH) g = 1.f - s * s;                 // saved = output
+    else if (act == VCG_ACT_LRELU) g = s >= 0.f ? 1.f : al;   // saved = output (slope > 0 keeps the sign)
+    else if (act == VCG_ACT_PRELU) { g = s > 0.f ? 1.f : al; dal += d * fminf(s, 0.f); }  // saved = input
+    else g = 1.f;
+    return d * g;
+}
+
+template <bool VEC>
 __global__ __launch_bounds__(256) void act_bwd_kernel(const float* saved, const float* dy, int n, int c, int hw,
                                                       int act, float act_alpha, const float* prelu, float* dx,
-                                                      float* part /* [n*c][gridDim.x] or null */) {
-    __shared__ float red[4];
+                                                      float* part_alpha, float* part_sum /* [n*c][gridDim.x] or null */) {
+    __shared__ float red[8];
     const int plane = blockIdx.y;
     const int ch = plane % c;
     const float al = (act == VCG_ACT_PRELU) ? prelu[ch] : act_alpha;
     const size_t base = (size_t)plane * hw;
-    float v[1] = {0.f};
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < hw; i += gridDim.x * 256) {
-        const float s = saved[base + i], d = dy[base + i];
-        float g;
-        if (act == VCG_ACT_TANH) g = 1.f - s * s;                 // saved = output
-        else if (act == VCG_ACT_LRELU) g = s >= 0.f ? 1.f : al;   // saved = output (slope > 0 keeps the sign)
-        else if (act == VCG_ACT_PRELU) { g = s > 0.f ? 1.f : al; v[0] += d * fminf(s, 0.f); }  // saved = input
-        else g = 1.f;
-        dx[base + i] = d * g;
+    float v[2] = {0.f, 0.f};   // dalpha partial, sum(dx) partial
+    if (VEC) {
+        for (int i = (blockIdx.x * 256 + threadIdx.x) * 4; i < hw; i += gridDim.x * 1024) {
+            const float4 s = *reinterpret_cast<const float4*>(saved + base + i);
+            const float4 d = *reinterpret_cast<const float4*>(dy + base + i);
+            float4 o;
+            o.x = act_bwd_one(s.x, d.x, act, al, v[0]);
+            o.y = act_bwd_one(s.y, d.y, act, al, v[0]);
+            o.z = act_bwd_one(s.z, d.z, act, al, v[0]);
+            o.w = act_bwd_one(s.w, d.w, act, al, v[0]);
+            v[1] += (o.x + o.y) + (o.z + o.w);
+            *reinterpret_cast<float4*>(dx + base + i) = o;
+        }
+    } else {
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < hw; i += gridDim.x * 256) {
+            const float o = act_bwd_one(saved[base + i], dy[base + i], act, al, v[0]);
+            v[1] += o;
+            dx[base + i] = o;
+        }
     }
-    if (part) {
-        block_sum<1>(v, red);
-        if (threadIdx.x == 0) part[(size_t)plane * gridDim.x + blockIdx.x] = v[0];
+    if (part_alpha || part_sum) {
+        block_sum<2>(v, red);
+        if (threadIdx.x == 0) {
+            if (part_alpha) part_alpha[(size_t)plane * gridDim.x + blockIdx.x] = v[0];
+            if (part_sum) part_sum[(size_t)plane * gridDim.x + blockIdx.x] = v[1];
+        }
     }
 }
 
@@ -139,6 +162,24 @@ __global__ __launch_bounds__(256) void adam_kernel(float* p, const float* g, flo
     p[i] = p[i] - lr_t * mi / (sqrtf(vi) + eps);
 }
 
+// same update with the step count t read from device memory: lr_t = lr*sqrt(1-b2^t)/(1-b1^t) is evaluated on
+// the device so that a captured hipGraph replays correctly as t advances
+__global__ __launch_bounds__(256) void adam_dev_kernel(float* p, const float* g, float* m, float* v, size_t count, float lr,
+                                                       float b1, float b2, float eps, const int* t_dev) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= count) return;
+    const float t = (float)(*t_dev + 1);
+    const float lr_t = lr * sqrtf(1.f - powf(b2, t)) / (1.f - powf(b1, t));
+    const float gi = g[i];
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    p[i] = p[i] - lr_t * mi / (sqrtf(vi) + eps);
+}
+
+__global__ void counter_add_kernel(int* c, int inc) { if (threadIdx.x == 0 && blockIdx.x == 0) *c += inc; }
+
 // ---- layout / value conversion at the frame edge ------------------------------------------------------
 __global__ void u8_to_nchw_kernel(const uint8_t* src, float* dst, int n, int h, int w, int c) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;  // index in dst (NCHW)
@@ -209,10 +250,10 @@ inline unsigned blocks_for(size_t count) { return (unsigned)((count + 255) / 256
 
 extern "C" {
 
-size_t vcg_act_bwd_workspace_bytes(int n, int c, int hw) { return (size_t)n * c * 64 * sizeof(float); }
+size_t vcg_act_bwd_workspace_bytes(int n, int c, int hw) { return (size_t)2 * n * c * 64 * sizeof(float); }
 
 int vcg_act_bwd(const float* saved, const float* dy, int n, int c, int hw, int act, float act_alpha,
-                const float* prelu_alpha, float* dx, float* dprelu_alpha, void* ws, size_t ws_bytes,
+                const float* prelu_alpha, float* dx, float* dprelu_alpha, float* dsum, void* ws, size_t ws_bytes,
                 vcg_stream_t stream) {
     VCG_CHECK_PTR(saved); VCG_CHECK_PTR(dy); VCG_CHECK_PTR(dx);
     if (n <= 0 || c <= 0 || hw <= 0 || (long)n * c > 65535) return VCG_E_SHAPE;
@@ -221,17 +262,29 @@ int vcg_act_bwd(const float* saved, const float* dy, int n, int c, int hw, int a
     int gx = ceil_div(hw, 256 * 4);
     if (gx > 64) gx = 64;
     if (gx < 1) gx = 1;
-    float* part = nullptr;
-    if (dprelu_alpha) {
+    float* part_alpha = nullptr;
+    float* part_sum = nullptr;
+    if (dprelu_alpha || dsum) {
         if (ws == nullptr || ws_bytes < vcg_act_bwd_workspace_bytes(n, c, hw)) return VCG_E_WORKSPACE;
-        part = (float*)ws;
+        if (dprelu_alpha) part_alpha = (float*)ws;
+        if (dsum) part_sum = (float*)ws + (size_t)n * c * 64;
     }
-    hipLaunchKernelGGL(act_bwd_kernel, dim3(gx, (unsigned)(n * c)), dim3(256), 0, st, saved, dy, n, c, hw, act,
-                       act_alpha, prelu_alpha, dx, part);
+    if (hw % 4 == 0) {
+        hipLaunchKernelGGL(act_bwd_kernel<true>, dim3(gx, (unsigned)(n * c)), dim3(256), 0, st, saved, dy, n, c, hw, act,
+                           act_alpha, prelu_alpha, dx, part_alpha, part_sum);
+    } else {
+        hipLaunchKernelGGL(act_bwd_kernel<false>, dim3(gx, (unsigned)(n * c)), dim3(256), 0, st, saved, dy, n, c, hw, act,
+                           act_alpha, prelu_alpha, dx, part_alpha, part_sum);
+    }
     VCG_LAUNCH_CHECK();
     if (dprelu_alpha) {
-        hipLaunchKernelGGL(plane_partial_final_kernel, dim3(ceil_div(c, 256)), dim3(256), 0, st, (const float*)part, n,
-                           c, gx, dprelu_alpha);
+        hipLaunchKernelGGL(plane_partial_final_kernel, dim3(ceil_div(c, 256)), dim3(256), 0, st, (const float*)part_alpha,
+                           n, c, gx, dprelu_alpha);
+        VCG_LAUNCH_CHECK();
+    }
+    if (dsum) {
+        hipLaunchKernelGGL(plane_partial_final_kernel, dim3(ceil_div(c, 256)), dim3(256), 0, st, (const float*)part_sum, n,
+                           c, gx, dsum);
         VCG_LAUNCH_CHECK();
     }
     return VCG_OK;
@@ -309,6 +362,20 @@ int vcg_adam_keras_multi(float* p, const float* g, float* m, float* v, size_t co
     if (count == 0) return VCG_OK;
     hipLaunchKernelGGL(adam_kernel, dim3(blocks_for(count)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, count, lr_t,
                        beta_1, beta_2, eps);
+    VCG_LAUNCH_CHECK();
+    return VCG_OK;
+}
+
+int vcg_adam_keras_multi_dev(float* p, const float* g, float* m, float* v, size_t count, float lr, float beta_1,
+                             float beta_2, float eps, int* t_dev, vcg_stream_t stream) {
+    VCG_CHECK_PTR(p); VCG_CHECK_PTR(g); VCG_CHECK_PTR(m); VCG_CHECK_PTR(v); VCG_CHECK_PTR(t_dev);
+    hipStream_t st = (hipStream_t)stream;
+    if (count) {
+        hipLaunchKernelGGL(adam_dev_kernel, dim3(blocks_for(count)), dim3(256), 0, st, p, g, m, v, count, lr, beta_1,
+                           beta_2, eps, (const int*)t_dev);
+        VCG_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(counter_add_kernel, dim3(1), dim3(64), 0, st, t_dev, 1);
     VCG_LAUNCH_CHECK();
     return VCG_OK;
 }

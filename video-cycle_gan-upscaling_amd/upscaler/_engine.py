@@ -247,18 +247,24 @@ class Conv2D(Layer):
         rt = self.rt
         x, y, d = ctx
         n = d.n
+        db_done = False
         if self.act != L.ACT_NONE:
+            # activation backward; the bias gradient (per-channel sum of dz) comes out of the same pass
             dz = rt.empty(*dy.shape)
+            db = self.ps.grad(self.name + "/bias", which).data_ptr() if param_grads else None
+            ws, wsn = rt.workspace(rt.lib.vcg_act_bwd_workspace_bytes(n, self.cout, d.oh * d.ow))
             L.check(rt.lib.vcg_act_bwd(y.data_ptr(), dy.data_ptr(), n, self.cout, d.oh * d.ow, self.act, float(self.alpha),
-                                       None, dz.data_ptr(), None, None, 0, rt.stream), "vcg_act_bwd[%s]" % self.name)
+                                       None, dz.data_ptr(), None, db, ws, wsn, rt.stream), "vcg_act_bwd[%s]" % self.name)
             dy = dz
+            db_done = True
         if param_grads:
             need = rt.lib.vcg_conv2d_wgrad_workspace_bytes(ctypes.byref(d))
             ws, wsn = rt.workspace(need)
             with Timed(rt, tag and tag + "_wgrad"):
                 L.check(rt.lib.vcg_conv2d_wgrad(ctypes.byref(d), x.data_ptr(), dy.data_ptr(),
                                                 self.ps.grad(self.name + "/kernel", which).data_ptr(),
-                                                self.ps.grad(self.name + "/bias", which).data_ptr(), ws, wsn, rt.stream),
+                                                None if db_done else self.ps.grad(self.name + "/bias", which).data_ptr(),
+                                                ws, wsn, rt.stream),
                         "vcg_conv2d_wgrad[%s]" % self.name)
         dx = None
         if need_dx:
@@ -319,19 +325,23 @@ class ConvT2D(Layer):
     def backward(self, ctx, dy, need_dx=True, param_grads=True, which=0, tag=None):
         rt = self.rt
         x, y, d = ctx
+        db_done = False
         if self.act != L.ACT_NONE:
             dz = rt.empty(*dy.shape)
+            db = self.ps.grad(self.name + "/bias", which).data_ptr() if param_grads else None
+            ws, wsn = rt.workspace(rt.lib.vcg_act_bwd_workspace_bytes(d.n, self.cout, d.oh * d.ow))
             L.check(rt.lib.vcg_act_bwd(y.data_ptr(), dy.data_ptr(), d.n, self.cout, d.oh * d.ow, self.act, float(self.alpha),
-                                       None, dz.data_ptr(), None, None, 0, rt.stream), "vcg_act_bwd[%s]" % self.name)
+                                       None, dz.data_ptr(), None, db, ws, wsn, rt.stream), "vcg_act_bwd[%s]" % self.name)
             dy = dz
+            db_done = True
         if param_grads:
             need = rt.lib.vcg_conv_transpose2d_wgrad_workspace_bytes(ctypes.byref(d))
             ws, wsn = rt.workspace(need)
             with Timed(rt, tag and tag + "_wgrad"):
                 L.check(rt.lib.vcg_conv_transpose2d_wgrad(ctypes.byref(d), x.data_ptr(), dy.data_ptr(),
                                                           self.ps.grad(self.name + "/kernel", which).data_ptr(),
-                                                          self.ps.grad(self.name + "/bias", which).data_ptr(), ws, wsn,
-                                                          rt.stream), "vcg_conv_transpose2d_wgrad[%s]" % self.name)
+                                                          None if db_done else self.ps.grad(self.name + "/bias", which).data_ptr(),
+                                                          ws, wsn, rt.stream), "vcg_conv_transpose2d_wgrad[%s]" % self.name)
         dx = None
         if need_dx:
             dx = rt.empty(d.n, self.cin, d.h, d.w)
@@ -431,7 +441,7 @@ class NormAct(Layer):
         if self.norm is None:
             ws, wsn = rt.workspace(lib.vcg_act_bwd_workspace_bytes(n, c, hw))
             L.check(lib.vcg_act_bwd(x.data_ptr(), dy.data_ptr(), n, c, hw, self.act, float(self.alpha), self._alpha_ptr(),
-                                    dx.data_ptr(), dalpha, ws, wsn, rt.stream), "vcg_act_bwd[%s]" % self.name)
+                                    dx.data_ptr(), dalpha, None, ws, wsn, rt.stream), "vcg_act_bwd[%s]" % self.name)
             return dx
         if saved is None:
             raise RuntimeError("backward through inference-mode normalisation is not defined")

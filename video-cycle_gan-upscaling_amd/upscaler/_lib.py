@@ -50,7 +50,7 @@ SIGNATURES = {
     "vcg_norm_act_bwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_int, c_float, _P, c_int,
                                  _P, _P, _P, _P, _P, c_size_t, _P]),
     "vcg_act_bwd_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
-    "vcg_act_bwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_float, _P, _P, _P, _P, c_size_t, _P]),
+    "vcg_act_bwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_float, _P, _P, _P, _P, _P, c_size_t, _P]),
     "vcg_channel_sum_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "vcg_channel_sum": (c_int, [_P, c_int, c_int, c_int, _P, _P, c_size_t, _P]),
     "vcg_dense_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P]),
@@ -62,6 +62,7 @@ SIGNATURES = {
     "vcg_fill": (c_int, [_P, c_size_t, c_float, _P]),
     "vcg_axpby": (c_int, [_P, _P, c_size_t, c_float, c_float, _P]),
     "vcg_adam_keras_multi": (c_int, [_P, _P, _P, _P, c_size_t, c_float, c_float, c_float, c_float, _P]),
+    "vcg_adam_keras_multi_dev": (c_int, [_P, _P, _P, _P, c_size_t, c_float, c_float, c_float, c_float, _P, _P]),
     "vcg_frames_u8_to_nchw": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
     "vcg_nchw_to_frames_u8": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
     "vcg_nhwc_to_nchw": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),

@@ -524,6 +524,8 @@ class GanTrainer:
         self.opt = optimizer
         self.g_slots, self.d_slots = _Slots(generator), _Slots(discriminator)
         self.pg = process_group
+        self._t_dev = None          # device copy of optimizer.iterations (graph-replayable Adam)
+        self._graph = None
 
     # -- pieces ---------------------------------------------------------------------------------------
     def _adam(self, model, slots, which=0):
@@ -533,10 +535,16 @@ class GanTrainer:
         if self.pg is not None:
             from . import _dist
             _dist.allreduce_mean(g, self.pg)
-        L.check(rt.lib.vcg_adam_keras_multi(ps.params.data_ptr(), g.data_ptr(), slots.m.data_ptr(), slots.v.data_ptr(),
-                                            ps.n_trainable, float(self.opt.lr_t()), float(self.opt.beta_1),
-                                            float(self.opt.beta_2), float(self.opt.epsilon), rt.stream),
-                "vcg_adam_keras_multi")
+        if self._t_dev is not None:
+            L.check(rt.lib.vcg_adam_keras_multi_dev(ps.params.data_ptr(), g.data_ptr(), slots.m.data_ptr(), slots.v.data_ptr(),
+                                                    ps.n_trainable, float(self.opt.lr), float(self.opt.beta_1),
+                                                    float(self.opt.beta_2), float(self.opt.epsilon), self._t_dev.data_ptr(),
+                                                    rt.stream), "vcg_adam_keras_multi_dev")
+        else:
+            L.check(rt.lib.vcg_adam_keras_multi(ps.params.data_ptr(), g.data_ptr(), slots.m.data_ptr(), slots.v.data_ptr(),
+                                                ps.n_trainable, float(self.opt.lr_t()), float(self.opt.beta_1),
+                                                float(self.opt.beta_2), float(self.opt.epsilon), rt.stream),
+                    "vcg_adam_keras_multi")
         self.opt.iterations += 1
         model.refresh()
 
@@ -634,6 +642,46 @@ class GanTrainer:
         ld = self.disc_loss_value(ld)
         lg = self.gan_loss_values(content, adv)
         return ld, lg[0], lg[1], lg[2]
+
+    # -- hipGraph: the whole loop body as ONE graph launch ------------------------------------------------
+    def capture_train_step(self, lr, hr):
+        """Capture predict -> disc_step -> gan_step for these (static-shape) device batches into a hipGraph.
+        Later ``train_step_graph(lr, hr)`` copies the new frames into the captured input buffers and replays:
+        ~700 kernel launches become one graph launch (no per-kernel host cost, no launch gaps).  Available when
+        no host read sits inside the step (Wasserstein / v1 losses, single process)."""
+        if self.pg is not None or (self.losses is not None and self.losses.relativistic):
+            raise NotImplementedError("graph capture needs a step without host reads or collectives inside")
+        rt = self.rt
+        if self._t_dev is None:
+            self._t_dev = torch.tensor([self.opt.iterations], dtype=torch.int32, device=rt.device)
+        self._g_lr, self._g_hr = lr.clone(), hr.clone()
+        self.train_step(self._g_lr, self._g_hr)        # eager warm-up with the device-side counter (lazy buffers exist)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        it0 = self.opt.iterations
+        with torch.cuda.graph(graph):
+            fake = self.predict(self._g_lr)
+            ld = self.disc_step(self._g_hr, fake)
+            content, adv = self.gan_step(self._g_lr, self._g_hr)
+        # capture only records: undo the host-side counter advance of the recording pass
+        self.opt.iterations = it0
+        self._graph, self._g_out = graph, (ld, content, adv)
+        return graph
+
+    def train_step_graph(self, lr=None, hr=None):
+        """Replay the captured loop body (optionally on new frames of the captured shape)."""
+        if self._graph is None:
+            raise RuntimeError("call capture_train_step first")
+        if lr is not None:
+            self._g_lr.copy_(lr)
+        if hr is not None:
+            self._g_hr.copy_(hr)
+        self._graph.replay()
+        self.opt.iterations += 2
+        ld, content, adv = self._g_out
+        ldv = self.disc_loss_value(ld)
+        lg = self.gan_loss_values(content, adv)
+        return ldv, lg[0], lg[1], lg[2]
 
 
 class TrainingModel:
