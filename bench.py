@@ -31,6 +31,10 @@ for p in (ROOT, PKG):
 
 PEAK_F32_MFMA_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 METRIC = "upscaled frames/s (train step, G+D fwd+bwd) at 256->512"
+# HBM traffic of one launch of the dominant kernel at the C2 shape, measured with rocprofv3 PMC counters in
+# separate passes (scripts/pmc_kbench.sh "trunk 3x3"): FETCH_SIZE 141.2 MiB x 2 (gfx950 reports half of a
+# coalesced read; calibrated on stats_partial_kernel reading 128 MiB -> 64.1) + WRITE_SIZE 128.0 MiB
+TRUNK_CONV_HBM_BYTES = int((2 * 141.2 + 128.0) * 1024 * 1024)
 
 
 class KernelProf:
@@ -190,7 +194,9 @@ def main():
         ach = flop_per_launch / (mean_ms * 1e-3) / 1e12
         roof = {"bound": "mfma", "kernel": "conv_fwd_kernel<3,3,1,8> (64->64 3x3 trunk conv, forward + dgrad)",
                 "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": TRUNK_CONV_HBM_BYTES if (h, args.batch) == (256, 8) else None,
+                "traffic_note": "HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction, calibrated on a "
+                                "128 MiB streaming read; + WRITE_SIZE): profiles/r01_pmc_trunk_conv.txt; algorithmic bytes 268.6e6",
                 "launches_timed": launches, "mean_launch_ms": round(mean_ms, 4),
                 "flop_per_launch": flop_per_launch, "how": roof_note}
 

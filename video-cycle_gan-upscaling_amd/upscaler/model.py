@@ -815,3 +815,10 @@ class GeneratorTrainingModel:
 def compile_training_model(upscaler, loss, optimizer=_DEFAULT_ADAM):
     """model.py:1130-1137"""
     return GeneratorTrainingModel(upscaler, loss, optimizer)
+
+
+# =================================================================================================
+# functional block API (model.py:15-27, 63-75) -- see _graph.py
+# =================================================================================================
+from ._graph import (Input, add, batch_norm, build_model, conv2d, downsampling_block, leaky_relu,  # noqa: E402,F401
+                     make_upscaler_orig_functional, prelu, residual_block, upsampling_block)
