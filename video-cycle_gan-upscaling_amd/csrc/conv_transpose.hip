@@ -33,7 +33,7 @@ constexpr int d_of(int k, int cb) { return (k - cb - phase_of(k, cb)) / 2; }
 constexpr int dmin_of(int K, int cb) { int m = 1000; for (int k = 0; k < K; ++k) m = d_of(k, cb) < m ? d_of(k, cb) : m; return m; }
 constexpr int dmax_of(int K, int cb) { int m = -1000; for (int k = 0; k < K; ++k) m = d_of(k, cb) > m ? d_of(k, cb) : m; return m; }
 
-template <int K, int CBY, int CBX, int CK>
+template <int K, int CBY, int CBX, int CK, int MT>
 struct ConvTCfg {
     static constexpr int QROWS = 4;  // one q-row per wave
     static constexpr int DMINY = dmin_of(K, CBY), DMAXY = dmax_of(K, CBY);
@@ -44,18 +44,19 @@ struct ConvTCfg {
     static constexpr int PLANE = NR * NC;
     static constexpr int T = K * K;
     static constexpr int IN_ELEMS = CK * PLANE;
-    static constexpr int W_ELEMS = CK * T * 64;
+    static constexpr int MB = 32 * MT;   // output channels per workgroup
+    static constexpr int W_ELEMS = CK * T * MB;
     static constexpr int IN_PT = (IN_ELEMS + 255) / 256;
     static constexpr int W_PT = (W_ELEMS + 255) / 256;
     static constexpr size_t LDS_BYTES = (size_t)(IN_ELEMS + W_ELEMS) * sizeof(float);
 };
 
-template <int K, int CBY, int CBX, int CK>
-__global__ __launch_bounds__(256) void convt_kernel(const ConvTParams p) {
-    using C = ConvTCfg<K, CBY, CBX, CK>;
+template <int K, int CBY, int CBX, int CK, int MT>
+__global__ __launch_bounds__(256, (MT == 1 ? 2 : 1)) void convt_kernel(const ConvTParams p) {
+    using C = ConvTCfg<K, CBY, CBX, CK, MT>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* s_in = smem;               // [CK][NR][NC]
-    float* s_w = smem + C::IN_ELEMS;  // [CK][T][64]
+    float* s_w = smem + C::IN_ELEMS;  // [CK][T][MB]
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int half = lane >> 5, l31 = lane & 31;
@@ -64,7 +65,7 @@ __global__ __launch_bounds__(256) void convt_kernel(const ConvTParams p) {
     const int tx = b % p.tiles_x;   b /= p.tiles_x;
     const int ty = b % p.tiles_y;   b /= p.tiles_y;
     const int n = b;
-    const int qx0 = tx * 32, qy0 = ty * C::QROWS, co0 = cb * 64;
+    const int qx0 = tx * 32, qy0 = ty * C::QROWS, co0 = cb * C::MB;
     const int gy0 = qy0 - C::DMAXY, gx0 = qx0 - C::DMAXX;
     const float* xn = p.x + (size_t)n * p.cin * p.h * p.w_;
 
@@ -83,7 +84,6 @@ __global__ __launch_bounds__(256) void convt_kernel(const ConvTParams p) {
         in_off[i] = off;
     }
     const int hw = p.h * p.w_;
-    const bool m_ok = co0 + lane < p.cout;
     auto load_chunk = [&](int ci0) {
         const float* xc = xn + (size_t)ci0 * hw;
         const unsigned lim = (unsigned)((p.cin - ci0) * hw);
@@ -96,11 +96,12 @@ __global__ __launch_bounds__(256) void convt_kernel(const ConvTParams p) {
         }
 #pragma unroll
         for (int i = 0; i < C::W_PT; ++i) {
-            const int q = wv + 4 * i;
+            const int e = tid + i * 256;
+            const int m = e % C::MB, q = e / C::MB;      // row q = (ci, tap), column m
             const int t = q % C::T, ci = q / C::T;
             const int ch = ci0 + ci;
-            const bool ok = ch < p.cin && m_ok;
-            const float v = p.w[ok ? (t * p.cin + ch) * p.cout + co0 + lane : 0];
+            const bool ok = e < C::W_ELEMS && ch < p.cin && co0 + m < p.cout;
+            const float v = p.w[ok ? (t * p.cin + ch) * p.cout + co0 + m : 0];
             rw[i] = ok ? v : 0.f;
         }
     };
@@ -117,19 +118,19 @@ __global__ __launch_bounds__(256) void convt_kernel(const ConvTParams p) {
         }
     };
 
-    f32x16 acc[2][2][2];  // [py][px][mt]
+    f32x16 acc[2][2][MT];  // [py][px][mt]
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int c = 0; c < 2; ++c)
 #pragma unroll
-            for (int m = 0; m < 2; ++m)
+            for (int m = 0; m < MT; ++m)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[a][c][m][r] = 0.f;
 
     // input row for tap-offset d: tile row = wv + DMAXY - d ; col = l31 + DMAXX - d
     const float* bbase = s_in + half * C::PLANE + wv * C::NC + l31;
-    const float* abase = s_w + half * C::T * 64 + l31;
+    const float* abase = s_w + half * C::T * C::MB + l31;
 
     const int nchunks = (p.cin + CK - 1) / CK;
     load_chunk(0);
@@ -149,12 +150,11 @@ __global__ __launch_bounds__(256) void convt_kernel(const ConvTParams p) {
                                        (C::DMAXX - (C::DMINX + ix))];
             // all A operands of this channel pair first (one batch of LDS reads), then the MFMAs: the
             // compiler overlaps the next pair's reads with this pair's 2*T MFMAs
-            float av[C::T][2];
+            float av[C::T][MT];
 #pragma unroll
-            for (int t = 0; t < C::T; ++t) {
-                av[t][0] = abase[(cp * 2 * C::T + t) * 64];
-                av[t][1] = abase[(cp * 2 * C::T + t) * 64 + 32];
-            }
+            for (int t = 0; t < C::T; ++t)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) av[t][mt] = abase[(cp * 2 * C::T + t) * C::MB + mt * 32];
 #pragma unroll
             for (int ky = 0; ky < K; ++ky) {
 #pragma unroll
@@ -162,8 +162,8 @@ __global__ __launch_bounds__(256) void convt_kernel(const ConvTParams p) {
                     const int t = ky * K + kx;
                     const int py = phase_of(ky, CBY), px = phase_of(kx, CBX);
                     const int iy = d_of(ky, CBY) - C::DMINY, ix = d_of(kx, CBX) - C::DMINX;
-                    acc[py][px][0] = mfma32(av[t][0], bv[iy][ix], acc[py][px][0]);
-                    acc[py][px][1] = mfma32(av[t][1], bv[iy][ix], acc[py][px][1]);
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) acc[py][px][mt] = mfma32(av[t][mt], bv[iy][ix], acc[py][px][mt]);
                 }
             }
         }
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(256) void convt_kernel(const ConvTParams p) {
     // guard-free path; none / LeakyReLU / PReLU share  v >= 0 ? v : v*slope  (slope 1 = identity).
     const int qy = qy0 + wv, qx = qx0 + l31;
     const bool vec_ok = (p.ow % 2) == 0;
-    const bool full = vec_ok && (co0 + 64 <= p.cout) && (2 * (qy0 + C::QROWS) <= p.oh) && (2 * (qx0 + 32) <= p.ow);
+    const bool full = vec_ok && (co0 + C::MB <= p.cout) && (2 * (qy0 + C::QROWS) <= p.oh) && (2 * (qx0 + 32) <= p.ow);
     const int plane = p.oh * p.ow;
     const size_t img = (size_t)n * p.cout * plane;
     float* yimg = p.y + img;
@@ -188,7 +188,7 @@ __global__ __launch_bounds__(256) void convt_kernel(const ConvTParams p) {
     auto emit = [&](auto guard_tag, auto res_tag) {
         constexpr bool GUARD = decltype(guard_tag)::value, RES = decltype(res_tag)::value;
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
+        for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = mt * 32 + mfma_row(r, lane);
@@ -236,15 +236,15 @@ __global__ __launch_bounds__(256) void convt_kernel(const ConvTParams p) {
     }
 }
 
-template <int K, int CBY, int CBX, int CK>
+template <int K, int CBY, int CBX, int CK, int MT>
 int launch_convt(ConvTParams p, hipStream_t st) {
-    using C = ConvTCfg<K, CBY, CBX, CK>;
+    using C = ConvTCfg<K, CBY, CBX, CK, MT>;
     p.tiles_x = ceil_div(ceil_div(p.ow, 2), 32);
     p.tiles_y = ceil_div(ceil_div(p.oh, 2), C::QROWS);
-    p.co_blocks = ceil_div(p.cout, 64);
+    p.co_blocks = ceil_div(p.cout, C::MB);
     const long grid = (long)p.tiles_x * p.tiles_y * p.co_blocks * p.n;
     if (grid <= 0 || grid > 0x7fffffffL) return VCG_E_SHAPE;
-    auto kern = convt_kernel<K, CBY, CBX, CK>;
+    auto kern = convt_kernel<K, CBY, CBX, CK, MT>;
     if (C::LDS_BYTES > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES);
@@ -271,10 +271,12 @@ int vcg_internal_convt(const float* x, const float* w, float* y, int n, int cin,
     if (p.act == VCG_ACT_TANH) return VCG_E_UNSUPPORTED;
     p.n = n; p.cin = cin; p.h = h; p.w_ = wd; p.cout = cout; p.oh = oh; p.ow = ow;
     if (n <= 0 || cin <= 0 || cout <= 0 || oh <= 0 || ow <= 0) return VCG_E_SHAPE;
-#define VCG_CT(K_, A_, B_, CK_) if (k == K_ && cby == A_ && cbx == B_) return launch_convt<K_, A_, B_, CK_>(p, st)
-    VCG_CT(3, 0, 0, 16); VCG_CT(3, 0, 1, 16); VCG_CT(3, 1, 0, 16); VCG_CT(3, 1, 1, 16);
-    VCG_CT(4, 1, 1, 16);
-    VCG_CT(5, 1, 1, 8); VCG_CT(5, 1, 2, 8); VCG_CT(5, 2, 1, 8); VCG_CT(5, 2, 2, 8);
+#define VCG_CT(K_, A_, B_, CK_, MT_) if (k == K_ && cby == A_ && cbx == B_) return launch_convt<K_, A_, B_, CK_, MT_>(p, st)
+    // MT = 1: 32 output channels per workgroup, 64 accumulator registers -> 2+ workgroups per CU overlap each
+    // other's staging and barriers (measured faster than 64 channels at one wave per SIMD)
+    VCG_CT(3, 0, 0, 16, 1); VCG_CT(3, 0, 1, 16, 1); VCG_CT(3, 1, 0, 16, 1); VCG_CT(3, 1, 1, 16, 1);
+    VCG_CT(4, 1, 1, 16, 1);
+    VCG_CT(5, 1, 1, 8, 2); VCG_CT(5, 1, 2, 8, 2); VCG_CT(5, 2, 1, 8, 2); VCG_CT(5, 2, 2, 8, 2);
 #undef VCG_CT
     return VCG_E_UNSUPPORTED;
 }

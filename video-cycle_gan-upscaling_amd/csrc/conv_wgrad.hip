@@ -35,11 +35,19 @@ struct WgradParams {
     int m_pad, j_pad;
 };
 
-template <int S, int NJ, int TH, int K>
+// NW waves per workgroup, two layouts of the 64-channel x JTILES block over the waves:
+//   MW = 2: every wave covers both 32-row m-tiles and NJ of the NW*NJ j-tiles (2*NJ accumulator tiles per wave;
+//           small register footprint -> 2-3 workgroups per CU overlap each other's staging and barriers);
+//   MW = 1: waves split the m-tiles too (wave = 1 m-tile x NJ j-tiles, JTILES = NW/2*NJ): the layout for the
+//           64-channel 3x3 / 5x5 blocks whose 18 / 26 j-tiles need 144-208 accumulator registers per wave.
+// Which layout serves which shape was measured (profiles/r01_kbench.txt).
+template <int S, int NW, int NJ, int MW, int TH, int K>
 struct WgCfg {
     static constexpr int T = K * K;
-    static constexpr int JCMAX = (2 * NJ * 32) / T;
-    static constexpr int AST = TH * 32 + 1;             // odd stride between m rows of the A tile
+    static constexpr int NT = 64 * NW;                   // threads per workgroup
+    static constexpr int JTILES = (MW == 2 ? NW : NW / 2) * NJ;   // j-tiles per block
+    static constexpr int JCMAX = (JTILES * 32) / T;      // B channels per block
+    static constexpr int AST = TH * 32 + 1;              // odd stride between m rows of the A tile
     static constexpr int BH = (TH - 1) * S + K;
     static constexpr int BW = 31 * S + K;
     // conflict-free gather: row stride = K and plane stride = K*K (mod 32) put element (jc,ky,kx) of a lane on
@@ -49,14 +57,22 @@ struct WgCfg {
     static constexpr int BPS = round_to(BH * BRS, (K * K) % 32);
     static constexpr int A_ELEMS = 64 * TH * 32;
     static constexpr int B_ELEMS = JCMAX * BH * BW;
-    static constexpr int A_PT = A_ELEMS / 256;
-    static constexpr int B_PT = (B_ELEMS + 255) / 256;
+    static constexpr int A_PT = (A_ELEMS + NT - 1) / NT;
+    // B staging: thread = (row group, column) over whole 32-column segments of the halo rows -- (channel, row)
+    // come from one small division per ROW instead of three per element -- plus a flat pass for the BW % 32
+    // remaining halo columns
+    static constexpr int RG = NT / 32;
+    static constexpr int ROWS = JCMAX * BH;
+    static constexpr int QSEG = BW / 32, REM = BW % 32;
+    static constexpr int RPT = (ROWS + RG - 1) / RG;
+    static constexpr int HPT = (ROWS * REM + NT - 1) / NT;
+    static constexpr int B_PT = RPT * QSEG + HPT;
     static constexpr size_t LDS_BYTES = ((size_t)64 * AST + (size_t)JCMAX * BPS + 64) * sizeof(float);
 };
 
-template <int S, int NJ, int TH, int K>
-__global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
-    using C = WgCfg<S, NJ, TH, K>;
+template <int S, int NW, int NJ, int MW, int TH, int K>
+__global__ __launch_bounds__(64 * NW, (MW * NJ * 16 > 100 ? 1 : 2)) void wgrad_kernel(const WgradParams p) {
+    using C = WgCfg<S, NW, NJ, MW, TH, K>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* s_a = smem;                 // [64][AST]
     float* s_b = smem + 64 * C::AST;   // [JCMAX][BH][BRS] (plane stride BPS)
@@ -75,7 +91,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
     int boff[NJ];
 #pragma unroll
     for (int i = 0; i < NJ; ++i) {
-        const int j = ((wv >> 1) * NJ + i) * 32 + l31;
+        const int j = ((MW == 2 ? wv : (wv >> 1)) * NJ + i) * 32 + l31;
         int o = 0;
         if (j < jvalid) {
             const int jc = j / C::T, t = j % C::T;
@@ -85,14 +101,17 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
         }
         boff[i] = o + half * S;
     }
-    const float* ap0 = s_a + ((wv & 1) * 32 + l31) * C::AST + half;
+    const float* ap0 = s_a + ((MW == 2 ? 0 : (wv & 1)) * 32 + l31) * C::AST + half;
 
-    f32x16 acc[NJ];
+    f32x16 acc[MW][NJ];
 #pragma unroll
-    for (int i = 0; i < NJ; ++i)
+    for (int m = 0; m < MW; ++m)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+        for (int i = 0; i < NJ; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][i][r] = 0.f;
     float dbacc = 0.f;
+    const bool do_db = p.dbpart != nullptr && jb == 0 && wv == 0;
 
     const int t_begin = slab * p.tiles_per_slab;
     const int t_end = min(t_begin + p.tiles_per_slab, p.tiles_total);
@@ -105,42 +124,71 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
         const int n = q;
         const int ax0 = tx * 32, ay0 = ty * TH;
         const float* An = p.A + (size_t)n * p.mtot * p.ah * p.aw;
+        // unconditional loads from clamped addresses, masked afterwards (no per-element branches)
 #pragma unroll
         for (int i = 0; i < C::A_PT; ++i) {
-            const int e = tid + i * 256;
+            const int e = tid + i * C::NT;
             const int c = e & 31, r = (e >> 5) % TH, m = e / (32 * TH);
             const int ay = ay0 + r, ax = ax0 + c;
-            const bool ok = m0 + m < p.mtot && ay < p.ah && ax < p.aw;
+            const bool ok = e < C::A_ELEMS && m0 + m < p.mtot && ay < p.ah && ax < p.aw;
             const float v = An[ok ? ((m0 + m) * p.ah + ay) * p.aw + ax : 0];
             ra[i] = ok ? v : 0.f;
         }
         const float* Bn = p.B + ((size_t)n * p.jctot + jc0) * p.bh * p.bw;
         const int by0 = ay0 * S - p.pt, bx0 = ax0 * S - p.pl;
+        const int c32 = tid & 31, rg = tid >> 5;
 #pragma unroll
-        for (int i = 0; i < C::B_PT; ++i) {
-            const int e = tid + i * 256;
-            const int jc = e / (C::BH * C::BW), rem = e % (C::BH * C::BW);
-            const int r = rem / C::BW, c = rem % C::BW;
+        for (int i = 0; i < C::RPT; ++i) {
+            const int row = rg + i * C::RG;
+            const int jc = row / C::BH, r = row % C::BH;
+            const int by = by0 + r;
+            const bool rok = row < C::ROWS && jc < jc_here && by >= 0 && by < p.bh;
+            const int rbase = (jc * p.bh + by) * p.bw + bx0;
+#pragma unroll
+            for (int q = 0; q < C::QSEG; ++q) {
+                const int bx = bx0 + q * 32 + c32;
+                const bool ok = rok && bx >= 0 && bx < p.bw;
+                const float v = Bn[ok ? rbase + q * 32 + c32 : 0];
+                rb[i * C::QSEG + q] = ok ? v : 0.f;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < C::HPT; ++i) {
+            const int e = tid + i * C::NT;
+            const int row = e / C::REM, c = C::QSEG * 32 + e % C::REM;
+            const int jc = row / C::BH, r = row % C::BH;
             const int by = by0 + r, bx = bx0 + c;
-            const bool ok = e < C::B_ELEMS && jc < jc_here && by >= 0 && by < p.bh && bx >= 0 && bx < p.bw;
+            const bool ok = row < C::ROWS && jc < jc_here && by >= 0 && by < p.bh && bx >= 0 && bx < p.bw;
             const float v = Bn[ok ? (jc * p.bh + by) * p.bw + bx : 0];
-            rb[i] = ok ? v : 0.f;
+            rb[C::RPT * C::QSEG + i] = ok ? v : 0.f;
         }
     };
     auto store_tile = [&]() {
 #pragma unroll
         for (int i = 0; i < C::A_PT; ++i) {
-            const int e = tid + i * 256;
-            const int c = e & 31, r = (e >> 5) % TH, m = e / (32 * TH);
-            s_a[m * C::AST + r * 32 + c] = ra[i];
+            const int e = tid + i * C::NT;
+            if (e < C::A_ELEMS) {
+                const int c = e & 31, r = (e >> 5) % TH, m = e / (32 * TH);
+                s_a[m * C::AST + r * 32 + c] = ra[i];
+            }
+        }
+        const int c32 = tid & 31, rg = tid >> 5;
+#pragma unroll
+        for (int i = 0; i < C::RPT; ++i) {
+            const int row = rg + i * C::RG;
+            if (row < C::ROWS) {
+                const int jc = row / C::BH, r = row % C::BH;
+#pragma unroll
+                for (int q = 0; q < C::QSEG; ++q) s_b[jc * C::BPS + r * C::BRS + q * 32 + c32] = rb[i * C::QSEG + q];
+            }
         }
 #pragma unroll
-        for (int i = 0; i < C::B_PT; ++i) {
-            const int e = tid + i * 256;
-            if (e < C::B_ELEMS) {
-                const int jc = e / (C::BH * C::BW), rem = e % (C::BH * C::BW);
-                const int r = rem / C::BW, c = rem % C::BW;
-                s_b[jc * C::BPS + r * C::BRS + c] = rb[i];
+        for (int i = 0; i < C::HPT; ++i) {
+            const int e = tid + i * C::NT;
+            const int row = e / C::REM, c = C::QSEG * 32 + e % C::REM;
+            if (row < C::ROWS) {
+                const int jc = row / C::BH, r = row % C::BH;
+                s_b[jc * C::BPS + r * C::BRS + c] = rb[C::RPT * C::QSEG + i];
             }
         }
     };
@@ -151,37 +199,40 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
         store_tile();
         __syncthreads();
         if (tile + 1 < t_end) load_tile(tile + 1);  // in flight during the MFMA loop
-        if (p.dbpart != nullptr && jb == 0) {
-            // bias gradient: thread t sums a quarter of row (t>>2) of the staged A tile
-            const float* row = s_a + (tid >> 2) * C::AST + (tid & 3) * (TH * 8);
+        if (do_db) {
+            // bias gradient: lane = channel row of the staged dy tile (odd row stride: conflict-free)
+            const float* row = s_a + lane * C::AST;
 #pragma unroll
-            for (int i = 0; i < TH * 8; ++i) dbacc += row[i];
+            for (int i = 0; i < TH * 32; ++i) dbacc += row[i];
         }
 #pragma unroll
         for (int r = 0; r < TH; ++r) {
 #pragma unroll
             for (int st = 0; st < 16; ++st) {
-                const float a = ap0[r * 32 + 2 * st];
+                float av[MW];
 #pragma unroll
-                for (int i = 0; i < NJ; ++i)
-                    acc[i] = mfma32(a, s_b[boff[i] + (r * S) * C::BRS + 2 * st * S], acc[i]);
+                for (int m = 0; m < MW; ++m) av[m] = ap0[m * 32 * C::AST + r * 32 + 2 * st];
+#pragma unroll
+                for (int i = 0; i < NJ; ++i) {
+                    const float bv = s_b[boff[i] + (r * S) * C::BRS + 2 * st * S];
+#pragma unroll
+                    for (int m = 0; m < MW; ++m) acc[m][i] = mfma32(av[m], bv, acc[m][i]);
+                }
             }
         }
     }
 
     // ---- write the partial block: rows m, cols j
-    float* out = p.part + ((size_t)slab * p.m_pad + m0 + (wv & 1) * 32) * p.j_pad + (size_t)jb * (2 * NJ * 32);
+    float* out = p.part + ((size_t)slab * p.m_pad + m0 + (MW == 2 ? 0 : (wv & 1)) * 32) * p.j_pad + (size_t)jb * (C::JTILES * 32);
 #pragma unroll
-    for (int i = 0; i < NJ; ++i) {
-        const int jcol = ((wv >> 1) * NJ + i) * 32 + l31;
+    for (int m = 0; m < MW; ++m)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) out[(size_t)mfma_row(r, lane) * p.j_pad + jcol] = acc[i][r];
-    }
-    if (p.dbpart != nullptr && jb == 0) {
-        dbacc += __shfl_xor(dbacc, 1, 64);
-        dbacc += __shfl_xor(dbacc, 2, 64);
-        if ((tid & 3) == 0) p.dbpart[(size_t)slab * p.m_pad + m0 + (tid >> 2)] = dbacc;
-    }
+        for (int i = 0; i < NJ; ++i) {
+            const int jcol = ((MW == 2 ? wv : (wv >> 1)) * NJ + i) * 32 + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) out[(size_t)(m * 32 + mfma_row(r, lane)) * p.j_pad + jcol] = acc[m][i][r];
+        }
+    if (do_db) p.dbpart[(size_t)slab * p.m_pad + m0 + lane] = dbacc;
 }
 
 struct ReduceParams {
@@ -238,26 +289,23 @@ __global__ __launch_bounds__(256) void wgrad_db_reduce_kernel(const float* dbpar
 }
 
 struct Plan {
-    int S, NJ, TH, K, jc, m_blocks, j_blocks, slabs, tiles_x, tiles_y, tiles_total, tiles_per_slab;
+    int S, NW, NJ, MW, TH, K, jc, m_blocks, j_blocks, slabs, tiles_x, tiles_y, tiles_total, tiles_per_slab;
     int m_pad, j_pad;
     size_t ws_part_bytes, ws_bytes;
     bool ok;
 };
 
-// instantiated (K, NJ) pairs; every pair exists for S = 1 and (except K = 9) S = 2
-inline int pick_nj(int K, int jtot) {
-    const int c3[3] = {1, 4, 9}, c4[3] = {1, 4, 8}, c5[2] = {4, 13}, c9[1] = {4};
-    const int* c; int n;
+// wave layout per kernel size / stride (measured choices): NW waves, NJ j-tiles per wave, MW m-tiles per wave
+inline void pick_layout(int K, int S, int jtot, int* nw, int* nj, int* mw) {
+    *mw = 2;
+    if (jtot <= 64) { *nw = 2; *nj = 1; return; }          // 3-channel first layers, 1-channel head
     switch (K) {
-        case 3: c = c3; n = 3; break;
-        case 4: c = c4; n = 3; break;
-        case 5: c = c5; n = 2; break;
-        case 9: c = c9; n = 1; break;
-        default: return -1;
+        case 3: if (jtot <= 256) { *nw = 4; *nj = 2; } else { *nw = 4; *nj = 9; *mw = 1; } return;   // 18 tiles = 64 channels
+        case 4: if (S == 2) { *nw = 4; *nj = 2; } else { *nw = 4; *nj = 8; *mw = 1; } return;        // 8 tiles = 16 ch / 16 tiles = 32 ch
+        case 5: if (jtot <= 256) { *nw = 4; *nj = 2; } else { *nw = 4; *nj = 13; *mw = 1; } return;  // 26 tiles = 33 channels
+        case 9: *nw = 4; *nj = 2; return;                                                             // 8 tiles = 3 channels
+        default: *nw = 0; *nj = 0; return;
     }
-    for (int i = 0; i < n; ++i)
-        if (2 * c[i] * 32 >= jtot) return c[i];   // smallest block that holds the whole j range
-    return c[n - 1];
 }
 
 Plan make_plan(int n, int mtot, int ah, int aw, int jctot, int kh, int kw, int S) {
@@ -267,9 +315,9 @@ Plan make_plan(int n, int mtot, int ah, int aw, int jctot, int kh, int kw, int S
     const int T = kh * kw;
     pl.S = S; pl.K = kh;
     pl.TH = (S == 1) ? 2 : 1;
-    pl.NJ = pick_nj(kh, jctot * T);
-    if (pl.NJ < 0) return pl;
-    const int cap = 2 * pl.NJ * 32;
+    pick_layout(kh, S, jctot * T, &pl.NW, &pl.NJ, &pl.MW);
+    if (pl.NW == 0) return pl;
+    const int cap = (pl.MW == 2 ? pl.NW : pl.NW / 2) * pl.NJ * 32;
     pl.jc = cap / T;
     if (pl.jc < 1) return pl;
     if (pl.jc > jctot) pl.jc = jctot;
@@ -278,9 +326,8 @@ Plan make_plan(int n, int mtot, int ah, int aw, int jctot, int kh, int kw, int S
     pl.tiles_x = ceil_div(aw, 32);
     pl.tiles_y = ceil_div(ah, pl.TH);
     pl.tiles_total = pl.tiles_x * pl.tiles_y * n;
-    // one workgroup per CU is resident for the big accumulator blocks (NJ >= 8: >256 registers per lane),
-    // so 256 workgroups fill the chip in one round and halve the partial-sum traffic
-    int slabs = ceil_div(pl.NJ >= 8 ? 256 : 512, pl.m_blocks * pl.j_blocks);
+    // big-accumulator layouts hold one workgroup per CU (256 fill the chip in one round); the small ones 2-3
+    int slabs = ceil_div(pl.MW == 1 ? 256 : 768, pl.m_blocks * pl.j_blocks);
     if (slabs > pl.tiles_total) slabs = pl.tiles_total;
     if (slabs < 1) slabs = 1;
     pl.tiles_per_slab = ceil_div(pl.tiles_total, slabs);
@@ -293,16 +340,17 @@ Plan make_plan(int n, int mtot, int ah, int aw, int jctot, int kh, int kw, int S
     return pl;
 }
 
-template <int S, int NJ, int TH, int K>
+template <int S, int NW, int NJ, int MW, int TH, int K>
 int launch_wgrad(const WgradParams& p, int grid, hipStream_t st) {
-    using C = WgCfg<S, NJ, TH, K>;
-    auto kern = wgrad_kernel<S, NJ, TH, K>;
+    using C = WgCfg<S, NW, NJ, MW, TH, K>;
+    static_assert(C::LDS_BYTES <= 160 * 1024, "wgrad tile does not fit the 160 KiB LDS");
+    auto kern = wgrad_kernel<S, NW, NJ, MW, TH, K>;
     if (C::LDS_BYTES > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES);
         if (e != hipSuccess) return (int)e;
     }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), C::LDS_BYTES, st, p);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(C::NT), C::LDS_BYTES, st, p);
     VCG_LAUNCH_CHECK();
     return VCG_OK;
 }
@@ -332,21 +380,22 @@ int vcg_internal_wgrad(const float* A, const float* B, float* dw, float* db, int
     p.m_pad = pl.m_pad; p.j_pad = pl.j_pad;
     const int grid = pl.slabs * pl.m_blocks * pl.j_blocks;
     int rc = VCG_E_UNSUPPORTED;
-#define VCG_WG(S_, NJ_, TH_, K_) \
-    if (S == S_ && pl.NJ == NJ_ && pl.K == K_) rc = launch_wgrad<S_, NJ_, TH_, K_>(p, grid, st)
-    VCG_WG(1, 1, 2, 3); VCG_WG(1, 4, 2, 3); VCG_WG(1, 9, 2, 3);
-    VCG_WG(2, 1, 1, 3); VCG_WG(2, 4, 1, 3); VCG_WG(2, 9, 1, 3);
-    VCG_WG(1, 1, 2, 4); VCG_WG(1, 4, 2, 4); VCG_WG(1, 8, 2, 4);
-    VCG_WG(2, 1, 1, 4); VCG_WG(2, 4, 1, 4); VCG_WG(2, 8, 1, 4);
-    VCG_WG(1, 4, 2, 5); VCG_WG(1, 13, 2, 5);
-    VCG_WG(2, 4, 1, 5); VCG_WG(2, 13, 1, 5);
-    VCG_WG(1, 4, 2, 9);
+#define VCG_WG(S_, NW_, NJ_, MW_, TH_, K_)                                                          \
+    if (S == S_ && pl.NW == NW_ && pl.NJ == NJ_ && pl.MW == MW_ && pl.K == K_ && pl.TH == TH_) \
+    rc = launch_wgrad<S_, NW_, NJ_, MW_, TH_, K_>(p, grid, st)
+    VCG_WG(1, 2, 1, 2, 2, 3); VCG_WG(1, 4, 2, 2, 2, 3); VCG_WG(1, 4, 9, 1, 2, 3);
+    VCG_WG(2, 2, 1, 2, 1, 3); VCG_WG(2, 4, 2, 2, 1, 3); VCG_WG(2, 4, 9, 1, 1, 3);
+    VCG_WG(1, 2, 1, 2, 2, 4); VCG_WG(1, 4, 8, 1, 2, 4);
+    VCG_WG(2, 2, 1, 2, 1, 4); VCG_WG(2, 4, 2, 2, 1, 4);
+    VCG_WG(1, 4, 2, 2, 2, 5); VCG_WG(1, 4, 13, 1, 2, 5);
+    VCG_WG(2, 4, 2, 2, 1, 5); VCG_WG(2, 4, 13, 1, 1, 5);
+    VCG_WG(1, 4, 2, 2, 2, 9);
 #undef VCG_WG
     if (rc != VCG_OK) return rc;
     ReduceParams r{};
     r.part = (const float*)ws; r.dbpart = p.dbpart; r.dw = dw; r.db = db;
     r.slabs = pl.slabs; r.m_pad = pl.m_pad; r.j_pad = pl.j_pad;
-    r.mtot = mtot; r.jctot = jctot; r.jc = pl.jc; r.jbw = 2 * pl.NJ * 32; r.T = kh * kw;
+    r.mtot = mtot; r.jctot = jctot; r.jc = pl.jc; r.jbw = (pl.MW == 2 ? pl.NW : pl.NW / 2) * pl.NJ * 32; r.T = kh * kw;
     r.ts = ts; r.sm = sm; r.sj = sj;
     const size_t total = (size_t)pl.m_pad * pl.j_pad;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, r);
