@@ -50,6 +50,67 @@ struct ConvCfg {
     static constexpr size_t LDS_BYTES = (size_t)(IN_ELEMS + W_ELEMS) * sizeof(float);
 };
 
+// ---- shared epilogue: y = act(acc + bias) + residual for a 64-channel x (8 rows x 32*XT cols) tile ----------
+template <int XT>
+__device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)[2][2][XT], int n, int co0, int oy0, int ox0,
+                                              int wv, int lane) {
+    constexpr int ROWS_ = 8;
+    const int half = lane >> 5, l31 = lane & 31;
+    // epilogue: y = act(acc + bias) + residual.  Interior tiles take a guard-free path.
+    const int ox = ox0 + l31;
+    const bool full = (co0 + 64 <= p.cout) && (oy0 + ROWS_ <= p.oh) && (ox0 + 32 * XT <= p.ow);
+    // 32-bit element offsets inside this image's [cout][oh][ow] block: one scalar base + a vector offset
+    const int plane = p.oh * p.ow;
+    const size_t img = (size_t)n * p.cout * plane;
+    float* yb = p.y + img;
+    const float* rb = p.residual ? p.residual + img : nullptr;
+    const int ob = (co0 + 4 * half) * plane + (oy0 + wv * 2) * p.ow + ox;
+    // none / LeakyReLU / PReLU share one straight-line form  v >= 0 ? v : v*slope  (slope 1 = identity);
+    // tanh is only offered by the small-M kernel (the API rejects it here).
+    const float* bp = p.bias ? p.bias : vcg_zero_word;
+    const int bmask = p.bias ? ~0 : 0;
+    const bool is_prelu = p.act == VCG_ACT_PRELU;
+    const float* ap = is_prelu ? p.prelu : vcg_zero_word;
+    const int amask = is_prelu ? ~0 : 0;
+    const float slope_u = (p.act == VCG_ACT_LRELU) ? p.alpha : 1.f;
+    auto emit = [&](auto guard_tag, auto res_tag) {
+        constexpr bool GUARD = decltype(guard_tag)::value, RES = decltype(res_tag)::value;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = mt * 32 + mfma_row(r, lane);
+                const int co = co0 + row;
+                const bool co_ok = !GUARD || co < p.cout;
+                const int cs = co_ok ? co : co0;
+                const float bv = bp[cs & bmask];
+                const float pa = ap[cs & amask];
+                const float al = is_prelu ? pa : slope_u;
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt) {
+#pragma unroll
+                    for (int xt = 0; xt < XT; ++xt) {
+                        const int o = ob + (row - 4 * half) * plane + rt * p.ow + xt * 32;
+                        if (!GUARD || (co_ok && oy0 + wv * 2 + rt < p.oh && ox + xt * 32 < p.ow)) {
+                            float v = acc[mt][rt][xt][r] + bv;
+                            v = v >= 0.f ? v : v * al;
+                            if (RES) v += rb[o];
+                            yb[o] = v;
+                        }
+                    }
+                }
+            }
+        }
+    };
+    using T_ = std::true_type;
+    using F_ = std::false_type;
+    if (full) {
+        if (rb) emit(F_{}, T_{}); else emit(F_{}, F_{});
+    } else {
+        if (rb) emit(T_{}, T_{}); else emit(T_{}, F_{});
+    }
+}
+
 template <int KH, int KW, int S, int CK, int XT>
 __global__ __launch_bounds__(256, (KH >= 9 ? 1 : 2)) void conv_fwd_kernel(const ConvParams p) {
     using C = ConvCfg<KH, KW, S, CK, XT>;
@@ -166,59 +227,109 @@ __global__ __launch_bounds__(256, (KH >= 9 ? 1 : 2)) void conv_fwd_kernel(const 
         }
     }
 
-    // epilogue: y = act(acc + bias) + residual.  Interior tiles take a guard-free path.
-    const int ox = ox0 + l31;
-    const bool full = (co0 + 64 <= p.cout) && (oy0 + C::ROWS <= p.oh) && (ox0 + 32 * XT <= p.ow);
-    // 32-bit element offsets inside this image's [cout][oh][ow] block: one scalar base + a vector offset
-    const int plane = p.oh * p.ow;
-    const size_t img = (size_t)n * p.cout * plane;
-    float* yb = p.y + img;
-    const float* rb = p.residual ? p.residual + img : nullptr;
-    const int ob = (co0 + 4 * half) * plane + (oy0 + wv * 2) * p.ow + ox;
-    // none / LeakyReLU / PReLU share one straight-line form  v >= 0 ? v : v*slope  (slope 1 = identity);
-    // tanh is only offered by the small-M kernel (the API rejects it here).
-    const float* bp = p.bias ? p.bias : vcg_zero_word;
-    const int bmask = p.bias ? ~0 : 0;
-    const bool is_prelu = p.act == VCG_ACT_PRELU;
-    const float* ap = is_prelu ? p.prelu : vcg_zero_word;
-    const int amask = is_prelu ? ~0 : 0;
-    const float slope_u = (p.act == VCG_ACT_LRELU) ? p.alpha : 1.f;
-    auto emit = [&](auto guard_tag, auto res_tag) {
-        constexpr bool GUARD = decltype(guard_tag)::value, RES = decltype(res_tag)::value;
+    conv_epilogue<XT>(p, acc, n, co0, oy0, ox0, wv, lane);
+}
+
+// ------------------------------------------------------------------------------------------------
+// <= 3 input channels (first 9x9 conv on RGB frames, model.py:275; data gradient of the final 9x9 conv, :290):
+// the generic kernel pairs CHANNELS in the MFMA's k dimension and would pad 3 channels to 4 (25 % of the
+// matrix work on zeros).  Here the whole (channel, ky, kx) range is one flat K axis staged once, and an MFMA
+// takes two CONSECUTIVE k: the second half-wave reads one element further along the tap row, with the two
+// row / channel wrap-arounds handled by two more per-lane base pointers chosen at compile time.
+// ------------------------------------------------------------------------------------------------
+template <int KH, int KW, int S>
+struct C3Cfg {
+    static constexpr int ROWS = 8;
+    static constexpr int IH = (ROWS - 1) * S + KH;
+    static constexpr int IW = 31 * S + KW;
+    static constexpr int PLANE = IH * IW;
+    static constexpr int T = KH * KW;
+    static constexpr int KT = 3 * T;                       // flat K
+    static constexpr int NP = (KT + 1) / 2;                // MFMA k-pairs
+    static constexpr int IN_ELEMS = 3 * PLANE;
+    static constexpr int W_ROWS = 2 * NP;                  // weight rows incl. one zero row when KT is odd
+    static constexpr int W_ELEMS = W_ROWS * 64;
+    static constexpr int IN_PT = (IN_ELEMS + 255) / 256;
+    static constexpr int W_PT = W_ELEMS / 256;
+    static constexpr size_t LDS_BYTES = (size_t)(IN_ELEMS + W_ELEMS) * sizeof(float);
+    static constexpr int off(int k) { return (k / T) * PLANE + ((k % T) / KW) * IW + (k % T) % KW; }
+    static constexpr int D_ROW = IW - (KW - 1);                              // kx wraps to the next tap row
+    static constexpr int D_CH = PLANE - (KH - 1) * IW - (KW - 1);            // last tap -> first tap of next channel
+};
+
+template <int KH, int KW, int S>
+__global__ __launch_bounds__(256, 2) void conv_c3_kernel(const ConvParams p) {
+    using C = C3Cfg<KH, KW, S>;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* s_in = smem;               // [3][IH][IW]
+    float* s_w = smem + C::IN_ELEMS;  // [W_ROWS][64]
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    int b = blockIdx.x;
+    const int cb = b % p.co_blocks; b /= p.co_blocks;
+    const int tx = b % p.tiles_x;   b /= p.tiles_x;
+    const int ty = b % p.tiles_y;   b /= p.tiles_y;
+    const int n = b;
+    const int ox0 = tx * 32, oy0 = ty * C::ROWS, co0 = cb * 64;
+    const int gy0 = oy0 * S - p.pad_top, gx0 = ox0 * S - p.pad_left;
+    const float* xn = p.x + (size_t)n * p.cin * p.h * p.w_;
+
+    // ---- stage everything once: input halo tile of all channels + the whole weight slab of this block
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = mt * 32 + mfma_row(r, lane);
-                const int co = co0 + row;
-                const bool co_ok = !GUARD || co < p.cout;
-                const int cs = co_ok ? co : co0;
-                const float bv = bp[cs & bmask];
-                const float pa = ap[cs & amask];
-                const float al = is_prelu ? pa : slope_u;
-#pragma unroll
-                for (int rt = 0; rt < 2; ++rt) {
-#pragma unroll
-                    for (int xt = 0; xt < XT; ++xt) {
-                        const int o = ob + (row - 4 * half) * plane + rt * p.ow + xt * 32;
-                        if (!GUARD || (co_ok && oy0 + wv * 2 + rt < p.oh && ox + xt * 32 < p.ow)) {
-                            float v = acc[mt][rt][xt][r] + bv;
-                            v = v >= 0.f ? v : v * al;
-                            if (RES) v += rb[o];
-                            yb[o] = v;
-                        }
-                    }
-                }
-            }
+    for (int i = 0; i < C::IN_PT; ++i) {
+        const int e = tid + i * 256;
+        if (e < C::IN_ELEMS) {
+            const int ci = e / C::PLANE, rem = e % C::PLANE;
+            const int r = rem / C::IW, c = rem % C::IW;
+            const int gy = gy0 + r, gx = gx0 + c;
+            const bool ok = ci < p.cin && gy >= 0 && gy < p.h && gx >= 0 && gx < p.w_;
+            const float v = xn[ok ? (ci * p.h + gy) * p.w_ + gx : 0];
+            s_in[e] = ok ? v : 0.f;
         }
-    };
-    using T_ = std::true_type;
-    using F_ = std::false_type;
-    if (full) {
-        if (rb) emit(F_{}, T_{}); else emit(F_{}, F_{});
-    } else {
-        if (rb) emit(T_{}, T_{}); else emit(T_{}, F_{});
     }
+#pragma unroll 4
+    for (int i = 0; i < C::W_PT; ++i) {
+        const int e = tid + i * 256;
+        const int m = e & 63, k = e >> 6;              // k = ci*T + tap
+        const int ci = k / C::T, t = k % C::T;
+        const int tap = p.flip ? (C::T - 1 - t) : t;
+        const bool ok = k < C::KT && ci < p.cin && co0 + m < p.cout;
+        const float v = p.w[ok ? (tap * p.cin + ci) * p.cout + co0 + m : 0];
+        s_w[e] = ok ? v : 0.f;
+    }
+    __syncthreads();
+
+    f32x16 acc[2][2][1];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][0][r] = 0.f;
+
+    const float* b0p = s_in + (wv * 2 * S) * C::IW + l31 * S;     // lanes 0-31: k even
+    const float* bb1 = b0p + half * 1;                             // lanes 32-63: next tap in the row
+    const float* bb2 = b0p + half * C::D_ROW;                      //              first tap of the next row
+    const float* bb3 = b0p + half * C::D_CH;                       //              first tap of the next channel
+    const float* abase = s_w + half * 64 + l31;
+#pragma unroll
+    for (int pr = 0; pr < C::NP; ++pr) {
+        constexpr int dummy = 0; (void)dummy;
+        const int k0 = 2 * pr, k1 = 2 * pr + 1;
+        const int o0 = C::off(k0);
+        const int d = (k1 < C::KT) ? (C::off(k1) - o0) : 1;       // past the end: weights are zero, any valid read
+        const float* bb = (d == 1) ? bb1 : (d == C::D_ROW ? bb2 : bb3);
+        const float a0 = abase[k0 * 64];
+        const float a1 = abase[k0 * 64 + 32];
+        const float v0 = bb[o0];
+        const float v1 = bb[o0 + S * C::IW];
+        acc[0][0][0] = mfma32(a0, v0, acc[0][0][0]);
+        acc[0][1][0] = mfma32(a0, v1, acc[0][1][0]);
+        acc[1][0][0] = mfma32(a1, v0, acc[1][0][0]);
+        acc[1][1][0] = mfma32(a1, v1, acc[1][1][0]);
+    }
+    conv_epilogue<1>(p, acc, n, co0, oy0, ox0, wv, lane);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -396,6 +507,17 @@ int launch_conv(ConvParams p, hipStream_t st) {
     return launch_with_lds(conv_fwd_kernel<KH, KW, S, CK, XT>, (int)grid, C::LDS_BYTES, p, st);
 }
 
+template <int KH, int KW, int S>
+int launch_c3(ConvParams p, hipStream_t st) {
+    using C = C3Cfg<KH, KW, S>;
+    p.tiles_x = ceil_div(p.ow, 32);
+    p.tiles_y = ceil_div(p.oh, C::ROWS);
+    p.co_blocks = ceil_div(p.cout, 64);
+    const long grid = (long)p.tiles_x * p.tiles_y * p.co_blocks * p.n;
+    if (grid <= 0 || grid > 0x7fffffffL) return VCG_E_SHAPE;
+    return launch_with_lds(conv_c3_kernel<KH, KW, S>, (int)grid, C::LDS_BYTES, p, st);
+}
+
 template <int KH, int KW, int CK>
 int launch_smallm(ConvParams p, hipStream_t st) {
     using C = SmallCfg<KH, KW, CK>;
@@ -435,6 +557,11 @@ int vcg_internal_conv(const float* x, const float* w, float* y, int n, int cin, 
         return VCG_E_UNSUPPORTED;
     }
     if (p.act == VCG_ACT_TANH) return VCG_E_UNSUPPORTED;   // tanh epilogue: small-M kernel only (<= 32/kw channels)
+    if (cin <= 3) {   // flat-K kernel: no channel padding (first conv on RGB, data gradient of a 3-channel conv)
+        if (kh == 9 && kw == 9 && stride == 1) return launch_c3<9, 9, 1>(p, st);
+        if (kh == 3 && kw == 3 && stride == 1) return launch_c3<3, 3, 1>(p, st);
+        if (kh == 4 && kw == 4 && stride == 2) return launch_c3<4, 4, 2>(p, st);
+    }
     // wide outputs use 64-column tiles (two MFMA x-tiles per wave: half the barriers and weight staging per
     // MFMA, and 1024 workgroups = 2 full rounds of 2 per CU at the C2 trunk shape instead of 2.67 rounds of 3)
     const bool wide = ow > 32;
