@@ -54,6 +54,12 @@ CONV_CASES = [
     (256, 512, 4, 1, 1, 1, 9, 9),
     (512, 1, 4, 1, 1, 1, 10, 10),
     (16, 1, 4, 1, 1, 2, 8, 70),
+    (256, 512, 3, 2, "same", 4, 32, 32),     # D block 4 at 128x128 frames, batch 4
+    (64, 128, 3, 2, "same", 4, 128, 128),    # D block 2
+    (64, 64, 3, 1, "same", 3, 40, 72),
+    (128, 256, 4, 2, 1, 2, 32, 32),
+    (3, 64, 4, 2, 1, 2, 64, 64),
+    (256, 3, 9, 1, "same", 2, 40, 72),
 ]
 
 
