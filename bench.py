@@ -145,17 +145,22 @@ def main():
             dist.barrier(group=group)
             torch.cuda.synchronize()
 
-    # One hipGraph per step (single process, Wasserstein losses: no host read or collective inside the step).
-    # Under DP the step is launched eagerly around the two RCCL all-reduces.
-    use_graph = (world == 1) and not args.no_graph
+    # One hipGraph per step (Wasserstein losses: no host read inside the step).  Under DP the step is three graphs
+    # cut at the two exchange points, with the two RCCL all-reduces issued eagerly between the replays.
+    use_graph = not args.no_graph
     step = trainer.train_step
     if use_graph:
         try:
             trainer.capture_train_step(lr, hr)
-            step = trainer.train_step_graph
         except Exception as e:      # capture unsupported on this stack: say so and run eagerly
             print("graph capture failed (%s: %s); running eagerly" % (type(e).__name__, e), file=sys.stderr)
             use_graph = False
+        if group is not None:       # all ranks must take the same path
+            ok = torch.tensor([1 if use_graph else 0], dtype=torch.int32, device=rt.device)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+            use_graph = bool(ok.item())
+        if use_graph:
+            step = trainer.train_step_graph
     for _ in range(args.warmup):
         step(lr, hr)
     dom_tags = ("trunk_conv", "trunk_conv_dgrad")
@@ -210,7 +215,7 @@ def main():
                                    % (2 * h, 2 * h, args.res_blocks, "PatchGAN-70" if args.disc == "patchgan" else "simple_512",
                                       args.batch),
                        "global_batch": args.batch * world, "frame": "%dx%d->%dx%d" % (h, h, 2 * h, 2 * h),
-                       "parallelism": "dp%d" % world, "launch": "hipGraph replay" if use_graph else "eager"},
+                       "parallelism": "dp%d" % world, "launch": ("hipGraph replay" if world == 1 else "3 hipGraphs per step around the 2 RCCL all-reduces") if use_graph else "eager"},
             "last_losses": [round(float(v), 6) for v in losses],
             "roofline": roof,
         }

@@ -1,0 +1,57 @@
+"""Data parallelism of the PRODUCT path on the GPU: two ranks (gloo, sharing the one GPU of the test box; on a
+node it is one RCCL rank per GPU, same code) train on the two halves of a batch; their weights after three
+steps must equal the single-process run on the whole batch -- instance-norm models, so that per-replica
+statistics do not change the maths.  Run eagerly and as the three-graph replay."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import report
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+WORKER = os.path.join(HERE, "_dp_gpu_worker.py")
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run(world, mode, out):
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(r), LOCAL_RANK=str(r),
+                   WORLD_SIZE=str(world), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, WORKER, out, mode], env=env))
+    for p in procs:
+        assert p.wait(timeout=600) == 0
+    return dict(np.load(out))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["eager", "graph"])
+def test_two_rank_step_equals_whole_batch_step(tmp_path, mode):
+    one = _run(1, "eager", str(tmp_path / "one.npz"))
+    two = _run(2, mode, str(tmp_path / "two.npz"))
+    worst = 0.0
+    names = [k for k in one if k != "losses" and not k.startswith("init/")]
+    for m in ("G/", "D/"):
+        # error of the three-step UPDATE relative to the model's largest update
+        upd = max(float(np.max(np.abs(one[k] - one["init/" + k]))) for k in names if k.startswith(m))
+        assert upd > 0
+        for k in names:
+            if k.startswith(m):
+                e = float(np.max(np.abs(two[k] - one[k]))) / upd
+                worst = max(worst, e)
+                assert e < 5e-3, (k, e)
+    le = float(np.max(np.abs(two["losses"] - one["losses"]) / (np.abs(one["losses"]) + 1e-3)))
+    report("dp2 (%s) vs whole batch: worst weight err=%.2e  loss err=%.2e" % (mode, worst, le))
+    assert le < 1e-3

@@ -18,7 +18,7 @@ def init_from_env(backend=None):
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":
-            torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+            torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1))
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend=backend)
     return dist.group.WORLD
@@ -28,6 +28,12 @@ def allreduce_mean(flat, group):
     """in-place mean over the ranks of one flat fp32 buffer (the model's whole gradient bucket)."""
     if group is None:
         return flat
+    if flat.is_cuda and dist.get_backend(group) == "gloo":
+        # test rig only (several gloo ranks sharing one GPU, tests/test_dp_gpu.py): stage through the host
+        host = flat.detach().cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+        flat.copy_(host.div_(dist.get_world_size(group)))
+        return flat
     dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
     flat.div_(dist.get_world_size(group))
     return flat
@@ -35,7 +41,12 @@ def allreduce_mean(flat, group):
 
 def broadcast_(flat, group, src=0):
     if group is not None:
-        dist.broadcast(flat, src=src, group=group)
+        if flat.is_cuda and dist.get_backend(group) == "gloo":
+            host = flat.detach().cpu()
+            dist.broadcast(host, src=src, group=group)
+            flat.copy_(host)
+        else:
+            dist.broadcast(flat, src=src, group=group)
     return flat
 
 

@@ -528,13 +528,20 @@ class GanTrainer:
         self._graph = None
 
     # -- pieces ---------------------------------------------------------------------------------------
+    def _sync_grads(self, model, which=0):
+        """DP: mean of the model's flat gradient bucket over the ranks (one RCCL all-reduce)."""
+        if self.pg is not None:
+            from . import _dist
+            _dist.allreduce_mean(model.ps.grads if which == 0 else model.ps.grads2, self.pg)
+
     def _adam(self, model, slots, which=0):
+        self._sync_grads(model, which)
+        self._apply_adam(model, slots, which)
+
+    def _apply_adam(self, model, slots, which=0):
         rt = self.rt
         ps = model.ps
         g = ps.grads if which == 0 else ps.grads2
-        if self.pg is not None:
-            from . import _dist
-            _dist.allreduce_mean(g, self.pg)
         if self._t_dev is not None:
             L.check(rt.lib.vcg_adam_keras_multi_dev(ps.params.data_ptr(), g.data_ptr(), slots.m.data_ptr(), slots.v.data_ptr(),
                                                     ps.n_trainable, float(self.opt.lr), float(self.opt.beta_1),
@@ -549,24 +556,42 @@ class GanTrainer:
         model.refresh()
 
     def _global_mean(self, t):
+        """mean over the GLOBAL batch, available on the device right away (relativistic losses feed it through a
+        non-linearity before back-prop: SURVEY.md section 8e)."""
         m = E.mean_scalar(self.rt, t)
         if self.pg is not None:
             from . import _dist
             _dist.allreduce_mean(m, self.pg)
         return m
 
+    def _mean(self, t):
+        """mean that only feeds a reported loss value: kept rank-local here, averaged over the ranks when the
+        value is read (``_host_scalars``), so that the step itself holds no scalar collective."""
+        if self.losses is not None and self.losses.relativistic:
+            return self._global_mean(t)
+        return E.mean_scalar(self.rt, t)
+
+    def _host_scalars(self, tensors):
+        """read device scalars (rank-local means over equal shards) as python floats of the global batch"""
+        v = torch.stack([x.reshape(()) for x in tensors])
+        if self.pg is not None:          # (already-global values are unchanged by the mean)
+            from . import _dist
+            _dist.allreduce_mean(v, self.pg)
+        return [float(x) for x in v.tolist()]
+
     # -- the three reference calls ----------------------------------------------------------------------
     def predict(self, lr_nchw):
         y, _ = self.G.forward(lr_nchw, training=False)
         return y
 
-    def disc_step(self, hr, fake):
-        """disc_train.train_on_batch (train_gan3.py:353 / train_gan.py:315).  hr, fake: device NCHW."""
+    def disc_step(self, hr, fake, apply=True):
+        """disc_train.train_on_batch (train_gan3.py:353 / train_gan.py:315).  hr, fake: device NCHW.
+        apply=False stops after the local gradients (the caller syncs and applies them)."""
         rt, D = self.rt, self.D
         if self.wiring == "gan2":
             out_r, tape_r = D.forward(hr, True, True)
             out_f, tape_f = D.forward(fake, True, True)
-            mr, mf = self._global_mean(out_r), self._global_mean(out_f)
+            mr, mf = self._mean(out_r), self._mean(out_f)
             if self.losses.relativistic:
                 delta = float(mr.item()) - float(mf.item())
                 val, g = _act_value_and_grad(self.losses.loss_activation_name, delta)
@@ -591,10 +616,11 @@ class GanTrainer:
             mr = E.mean_scalar(rt, out[:nb])
             mf = E.mean_scalar(rt, out[nb:])
             loss = (mr, mf, nb * per / tot, (tot - nb * per) / tot)
-        self._adam(D, self.d_slots)
+        if apply:
+            self._adam(D, self.d_slots)
         return loss
 
-    def gan_step(self, lr, hr):
+    def gan_step(self, lr, hr, apply=True):
         """gan_train.train_on_batch (train_gan3.py:354 / train_gan.py:317)."""
         rt, G, D = self.rt, self.G, self.D
         fake, gtape = G.forward(lr, True)
@@ -605,7 +631,7 @@ class GanTrainer:
         L.check(rt.lib.vcg_pixel_loss(fake.data_ptr(), hr.data_ptr(), fake.numel(),
                                       L.LOSS_MSE if self.content_kind == "mse" else L.LOSS_MAE, self.cw, content.data_ptr(),
                                       dfake.data_ptr(), ws, wsn, rt.stream), "vcg_pixel_loss")
-        mf = self._global_mean(out_f)
+        mf = self._mean(out_f)
         adv = mf
         g = 1.0
         if self.wiring == "gan2" and self.losses.relativistic:
@@ -616,21 +642,24 @@ class GanTrainer:
         d_adv = D.backward(dtape, E.filled_like(rt, out_f, self.dw * g / out_f.numel()), True, False, 0)
         E.axpby(rt, d_adv, dfake, 1.0, 1.0)
         G.backward(gtape, dfake, 0)
-        self._adam(G, self.g_slots)
+        if apply:
+            self._adam(G, self.g_slots)
         return content, adv
 
     # -- loss read-back ---------------------------------------------------------------------------------
     def disc_loss_value(self, loss):
         if isinstance(loss, tuple):
+            mr, mf = self._host_scalars(loss[:2])
             if len(loss) == 2:
-                return float(loss[0].item()) - float(loss[1].item())
-            mr, mf, wr, wf = loss
-            return float(mr.item()) * wr - float(mf.item()) * wf
+                return mr - mf
+            return mr * loss[2] - mf * loss[3]
         return float(loss)
 
     def gan_loss_values(self, content, adv):
-        c = float(content.item())
-        a = float(adv.item()) if isinstance(adv, torch.Tensor) else float(adv)
+        if isinstance(adv, torch.Tensor):
+            c, a = self._host_scalars([content, adv])
+        else:
+            c, a = self._host_scalars([content])[0], float(adv)
         return [self.cw * c + self.dw * a, c, a]
 
     def train_step(self, lr, hr):
@@ -643,30 +672,51 @@ class GanTrainer:
         lg = self.gan_loss_values(content, adv)
         return ld, lg[0], lg[1], lg[2]
 
-    # -- hipGraph: the whole loop body as ONE graph launch ------------------------------------------------
+    # -- hipGraph: the whole loop body as ONE graph launch (three around the two all-reduces under DP) ------
     def capture_train_step(self, lr, hr):
         """Capture predict -> disc_step -> gan_step for these (static-shape) device batches into a hipGraph.
         Later ``train_step_graph(lr, hr)`` copies the new frames into the captured input buffers and replays:
         ~700 kernel launches become one graph launch (no per-kernel host cost, no launch gaps).  Available when
-        no host read sits inside the step (Wasserstein / v1 losses, single process)."""
-        if self.pg is not None or (self.losses is not None and self.losses.relativistic):
-            raise NotImplementedError("graph capture needs a step without host reads or collectives inside")
+        no host read sits inside the step (Wasserstein / v1 losses).
+
+        Under data parallelism the step is cut at its two exchange points into three graphs
+            A: predict, D forward x2, D backward x2        -> all-reduce(D gradient bucket)
+            B: Adam(D), G forward, D forward, D/G backward -> all-reduce(G gradient bucket)
+            C: Adam(G)
+        and the two RCCL all-reduces are issued eagerly between the replays (collectives stay outside the
+        graphs: nothing about RCCL capture is assumed)."""
+        if self.losses is not None and self.losses.relativistic:
+            raise NotImplementedError("graph capture needs a step without host reads inside")
         rt = self.rt
         if self._t_dev is None:
             self._t_dev = torch.tensor([self.opt.iterations], dtype=torch.int32, device=rt.device)
         self._g_lr, self._g_hr = lr.clone(), hr.clone()
         self.train_step(self._g_lr, self._g_hr)        # eager warm-up with the device-side counter (lazy buffers exist)
         torch.cuda.synchronize()
-        graph = torch.cuda.CUDAGraph()
         it0 = self.opt.iterations
-        with torch.cuda.graph(graph):
-            fake = self.predict(self._g_lr)
-            ld = self.disc_step(self._g_hr, fake)
-            content, adv = self.gan_step(self._g_lr, self._g_hr)
+        if self.pg is None:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                fake = self.predict(self._g_lr)
+                ld = self.disc_step(self._g_hr, fake)
+                content, adv = self.gan_step(self._g_lr, self._g_hr)
+            graphs = [graph]
+        else:
+            ga, gb, gc = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            with torch.cuda.graph(ga):
+                fake = self.predict(self._g_lr)
+                ld = self.disc_step(self._g_hr, fake, apply=False)
+            pool = ga.pool()
+            with torch.cuda.graph(gb, pool=pool):
+                self._apply_adam(self.D, self.d_slots)
+                content, adv = self.gan_step(self._g_lr, self._g_hr, apply=False)
+            with torch.cuda.graph(gc, pool=pool):
+                self._apply_adam(self.G, self.g_slots)
+            graphs = [ga, gb, gc]
         # capture only records: undo the host-side counter advance of the recording pass
         self.opt.iterations = it0
-        self._graph, self._g_out = graph, (ld, content, adv)
-        return graph
+        self._graph, self._g_out = graphs, (ld, content, adv)
+        return graphs[0] if len(graphs) == 1 else graphs
 
     def train_step_graph(self, lr=None, hr=None):
         """Replay the captured loop body (optionally on new frames of the captured shape)."""
@@ -676,7 +726,15 @@ class GanTrainer:
             self._g_lr.copy_(lr)
         if hr is not None:
             self._g_hr.copy_(hr)
-        self._graph.replay()
+        if len(self._graph) == 1:
+            self._graph[0].replay()
+        else:
+            ga, gb, gc = self._graph
+            ga.replay()
+            self._sync_grads(self.D)
+            gb.replay()
+            self._sync_grads(self.G)
+            gc.replay()
         self.opt.iterations += 2
         ld, content, adv = self._g_out
         ldv = self.disc_loss_value(ld)
