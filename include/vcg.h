@@ -170,6 +170,41 @@ int vcg_nchw_to_frames_u8(const float* src, uint8_t* dst, int n, int h, int w, i
 int vcg_nhwc_to_nchw(const float* src, float* dst, int n, int h, int w, int c, vcg_stream_t stream);
 int vcg_nchw_to_nhwc(const float* src, float* dst, int n, int h, int w, int c, vcg_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * bf16-storage path (BASELINE.json configs C3-C5): activations bf16 NHWC, weights bf16 packed
+ * [tap][out-channel][in-channel], fp32 accumulation (v_mfma_f32_32x32x16_bf16) and fp32 epilogue arithmetic.
+ * ------------------------------------------------------------------------------------------------------------ */
+
+/* y = act(acc * scale[c] + shift[c]) + residual.  scale/shift: fp32 per out-channel or NULL (1 / 0) -- the
+ * inference-mode BatchNormalization folded behind the convolution (Keras: upscaling/upscaler/model.py:20,23,284;
+ * shift also carries the Conv2D bias); act: VCG_ACT_NONE / _LRELU (act_alpha) / _PRELU (prelu_alpha[c], model.py:21);
+ * residual: bf16 NHWC tensor of the output's shape or NULL (the block's Add, model.py:25,285). */
+typedef struct vcg_epilogue_bf16 {
+    const void* scale;
+    const void* shift;
+    int32_t act;
+    float act_alpha;
+    const void* prelu_alpha;
+    const void* residual;
+} vcg_epilogue_bf16;
+
+/* fp32 kernel -> packed bf16.  out[tap'][i][j] (j contiguous) = transpose ? w[tap][j][i] : w[tap][i][j], with
+ * tap' = flip ? taps-1-tap : tap.  Conv2D forward from Keras' (kh,kw,in,out): a=out, b=in, transpose=1, flip=0;
+ * its data gradient: a=in, b=out, transpose=0, flip=1; Conv2DTranspose (kh,kw,out,in) forward: a=out, b=in,
+ * transpose=0, flip=0. */
+int vcg_pack_conv_kernel_bf16(const void* w, int32_t taps, int32_t a, int32_t b, int32_t transpose, int32_t flip, void* out,
+                              hipStream_t stream);
+
+/* layout + precision change at the edge of the bf16 path */
+int vcg_f32_nchw_to_bf16_nhwc(const void* x, void* y, int32_t n, int32_t c, int32_t h, int32_t w, hipStream_t stream);
+int vcg_bf16_nhwc_to_f32_nchw(const void* x, void* y, int32_t n, int32_t c, int32_t h, int32_t w, hipStream_t stream);
+
+/* Conv2D forward on bf16 NHWC (replaces keras Conv2D [+BatchNormalization(inference)+PReLU+Add] at
+ * upscaling/upscaler/model.py:19-25,283-285).  Instantiated: 3x3 stride 1 'same' 64->64 (generator trunk);
+ * other shapes return VCG_E_UNSUPPORTED. */
+int vcg_conv2d_bf16_fwd(const vcg_conv_desc* d, const void* x, const void* w_packed, void* y, const vcg_epilogue_bf16* ep,
+                        hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

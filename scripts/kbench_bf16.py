@@ -1,0 +1,59 @@
+"""Micro-benchmark of the bf16-storage kernels at the C5 shapes (batch 32, 256x256 -> 512x512):
+HIP-event time per launch, TFLOP/s against the dense bf16 MFMA peak and algorithmic GB/s against HBM.
+python scripts/kbench_bf16.py [batch]"""
+import ctypes
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "video-cycle_gan-upscaling_amd"))
+
+import torch
+
+from upscaler import _engine as E
+from upscaler import _lib as L
+
+PEAK_TF, PEAK_GBS = 2500.0, 8000.0
+
+
+def timeit(fn, iters=20, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def main():
+    B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+    rt = E.Runtime.get()
+    dev = rt.device
+    h = w = 256
+    x = torch.randn(B, h, w, 64, device=dev).to(torch.bfloat16)
+    res = torch.randn(B, h, w, 64, device=dev).to(torch.bfloat16)
+    y = torch.empty_like(x)
+    wk = (torch.randn(9, 64, 64, device=dev) * 0.05).to(torch.bfloat16)
+    sc = torch.rand(64, device=dev) + 0.5
+    sh = torch.rand(64, device=dev)
+    al = torch.rand(64, device=dev)
+    d = L.ConvDesc(B, 64, h, w, 64, h, w, 3, 3, 1, 1, 1)
+    flop = 2.0 * 64 * 64 * 9 * h * w * B
+    for name, ep, nbytes in (
+            ("trunk 3x3 64->64 plain", L.EpilogueBf16(None, None, L.ACT_NONE, 0.0, None, None), 2 * x.numel() * 2),
+            ("trunk + BN-fold + PReLU", L.EpilogueBf16(sc.data_ptr(), sh.data_ptr(), L.ACT_PRELU, 0.0, al.data_ptr(), None), 2 * x.numel() * 2),
+            ("trunk + BN-fold + Add", L.EpilogueBf16(sc.data_ptr(), sh.data_ptr(), L.ACT_NONE, 0.0, None, res.data_ptr()), 3 * x.numel() * 2)):
+        def run():
+            L.check(rt.lib.vcg_conv2d_bf16_fwd(ctypes.byref(d), x.data_ptr(), wk.data_ptr(), y.data_ptr(), ctypes.byref(ep), rt.stream), name)
+        ms = timeit(run)
+        print("%-28s B=%d  %.3f ms  %7.1f TFLOP/s (%.1f%% of %.0f)  %6.0f GB/s algorithmic (%.1f%% of %.0f)"
+              % (name, B, ms, flop / ms / 1e9, 100 * flop / ms / 1e9 / PEAK_TF, PEAK_TF, nbytes / ms / 1e6,
+                 100 * nbytes / ms / 1e6 / PEAK_GBS, PEAK_GBS), flush=True)
+
+
+if __name__ == "__main__":
+    main()

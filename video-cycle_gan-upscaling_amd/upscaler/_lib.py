@@ -26,10 +26,16 @@ class Epilogue(ctypes.Structure):
                 ("residual", c_void_p)]
 
 
+class EpilogueBf16(ctypes.Structure):
+    _fields_ = [("scale", c_void_p), ("shift", c_void_p), ("act", c_int32), ("act_alpha", c_float),
+                ("prelu_alpha", c_void_p), ("residual", c_void_p)]
+
+
 # name -> (restype, argtypes); every symbol include/vcg.h declares
 _P = c_void_p
 _D = POINTER(ConvDesc)
 _E = POINTER(Epilogue)
+_EB = POINTER(EpilogueBf16)
 SIGNATURES = {
     "vcg_version": (c_char_p, []),
     "vcg_error_string": (c_char_p, [c_int]),
@@ -67,6 +73,11 @@ SIGNATURES = {
     "vcg_nchw_to_frames_u8": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
     "vcg_nhwc_to_nchw": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
     "vcg_nchw_to_nhwc": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
+    # bf16-storage path
+    "vcg_pack_conv_kernel_bf16": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, _P]),
+    "vcg_f32_nchw_to_bf16_nhwc": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
+    "vcg_bf16_nhwc_to_f32_nchw": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
+    "vcg_conv2d_bf16_fwd": (c_int, [_D, _P, _P, _P, _EB, _P]),
 }
 
 _lib = None
