@@ -21,6 +21,14 @@ __device__ __forceinline__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 
+// v_permlane32_swap: lanes 32-63 of a <-> lanes 0-31 of b
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void swap32(float& a, float& b) {
+    const u32x2 sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    a = __uint_as_float(sw.x);
+    b = __uint_as_float(sw.y);
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // layout / packing helpers
 // ---------------------------------------------------------------------------------------------------------------
@@ -80,19 +88,28 @@ __global__ void bf16_nhwc_to_f32_nchw_kernel(const __bf16* __restrict__ x, float
 // ---------------------------------------------------------------------------------------------------------------
 // 3x3 stride-1 'same' convolution, 64 -> 64 channels: the generator trunk
 // ---------------------------------------------------------------------------------------------------------------
-// Persistent workgroups of 8 waves.  LDS: all 9x64x64 weights (72 KiB, loaded once) + one 18x34-pixel halo tile
-// (76.5 KiB).  Both images hold 128-byte rows (one pixel / one out-channel x 64 in-channels) whose eight 16-byte
-// chunks are XOR-swizzled with (index>>1)&7: the ds_read_b128 of the 16-lane groups {0-3,12-15,20-27},
-// {4-11,16-19,28-31} (MI355X_MICROARCH.md, LDS) then touches all 64 banks once, for every tap shift.
-// Wave w owns output rows 2w, 2w+1 of the 16x32 tile: a 64-channel x 64-pixel accumulator (4 MFMA tiles, 64 VGPRs)
-// fed by 2 weight + 2 pixel fragment reads per 4 MFMAs.  The next tile's halo is fetched into registers before the
-// MFMA loop and written to LDS after it.
-constexpr int TR = 16, TC = 32, HR = TR + 2, HC = TC + 2;
+// At bf16 this convolution is HBM-bound even at the full MFMA rate (per 16x32 pixels: 142 KB of traffic against
+// 9.2 k MFMA cycles per SIMD), so the kernel is organised around keeping loads AND stores in flight under the MFMAs:
+//   * persistent workgroups of 8 waves: 6 compute waves + 2 loader waves (wave-specialised: vmcnt is per wave
+//     and retires in order, so a wave that both prefetches and stores ends up draining its stores before it may
+//     touch the prefetched registers; with the roles split, neither side ever waits for the other's traffic);
+//   * LDS: all 9x64x64 weights (72 KiB, loaded once) + one 14x34-pixel halo tile (59.5 KiB) + 768 B of epilogue
+//     parameters.  Both images hold 128-byte rows (one pixel / one out-channel x 64 in-channels) whose eight 16-byte
+//     chunks are XOR-swizzled with (index>>1)&7: the ds_read_b128 of the 16-lane groups {0-3,12-15,20-27},
+//     {4-11,16-19,28-31} (MI355X_MICROARCH.md, LDS) then touches all 64 banks once, for every tap shift;
+//   * compute wave w owns output rows 2w, 2w+1 of the 12x32 tile: a 64-channel x 64-pixel accumulator (4 MFMA tiles,
+//     64 VGPRs), operand fragments double-buffered in registers (reads of k-step i+1 issued before the MFMAs of i);
+//   * loader waves fetch the next tile's halo into registers during the MFMA phase and write it to LDS between the
+//     two barriers that end a tile, while the compute waves run their epilogue.
+constexpr int NCW = 6, NLW = 2;             // compute / loader waves
+constexpr int TR = 2 * NCW, TC = 32, HR = TR + 2, HC = TC + 2;
 constexpr int ROWB = HC * 128;              // bytes per halo row
-constexpr int XB = HR * ROWB;               // 78336
+constexpr int XB = HR * ROWB;               // 60928
 constexpr int WB = 9 * 64 * 128;            // 73728
-constexpr int NCHUNK = HR * HC * 8;         // 16-byte chunks per halo tile (4896)
-constexpr int NPRE = (NCHUNK + 511) / 512;  // per-thread prefetch registers (10)
+constexpr int PB = 3 * 64 * 4;              // per-channel epilogue parameters: scale, shift, negative-side slope
+constexpr int NCHUNK = HR * HC * 8;         // 16-byte chunks per halo tile (3808)
+constexpr int NT = (NCW + NLW) * 64;
+constexpr int NPRE = (NCHUNK + NLW * 64 - 1) / (NLW * 64);   // per-loader-thread prefetch registers (30)
 
 struct C3Params {
     const uint4* x;
@@ -107,17 +124,75 @@ struct C3Params {
     float act_alpha;
 };
 
-__global__ __launch_bounds__(512, 1) void conv3x3_c64_bf16_kernel(C3Params p) {
+// workgroup barrier ordering LDS only: global stores stay in flight across it
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+__global__ __launch_bounds__(NT, 1) void conv3x3_c64_bf16_kernel(C3Params p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* wl = smem;
     unsigned char* xl = smem + WB;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, r = lane & 31, hh = lane >> 5;
+    float* prm = (float*)(smem + WB + XB);
+    const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, hh = lane >> 5;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-    for (int c = tid; c < 9 * 64 * 8; c += 512) {
+    for (int c = tid; c < 9 * 64 * 8; c += NT) {
         const int chunk = c & 7, co = (c >> 3) & 63, tap = c >> 9;
         *(uint4*)(wl + tap * 8192 + co * 128 + ((chunk ^ ((co >> 1) & 7)) << 4)) = p.w[c];
     }
+    if (tid < 64) {
+        prm[tid] = p.scale ? p.scale[tid] : 1.f;
+        prm[64 + tid] = p.shift ? p.shift[tid] : 0.f;
+        prm[128 + tid] = p.act == VCG_ACT_PRELU ? p.alpha[tid] : (p.act == VCG_ACT_LRELU ? p.act_alpha : 1.f);
+    }
 
+    if (wv >= NCW) {
+        // ------------------------------------------------------------------------------------------ loader waves
+        const int lt = tid - NCW * 64;
+        uint4 pre[NPRE];
+        unsigned okmask = 0;
+        auto fetch = [&](int tile) {
+            const int txi = tile % p.tiles_x, t2 = tile / p.tiles_x, tyi = t2 % p.tiles_y, img = t2 / p.tiles_y;
+            const int y0 = tyi * TR - 1, x0 = txi * TC - 1;
+            okmask = 0;
+#pragma unroll
+            for (int i = 0; i < NPRE; ++i) {
+                const int c = min(lt + NLW * 64 * i, NCHUNK - 1);     // the tail re-reads the last chunk: same data, same slot
+                const int pix = c >> 3, row = pix / HC, col = pix - row * HC;
+                const int gy = y0 + row, gx = x0 + col;
+                const bool ok = (unsigned)gy < (unsigned)p.h && (unsigned)gx < (unsigned)p.w_;
+                const int cy = min(max(gy, 0), p.h - 1), cx = min(max(gx, 0), p.w_ - 1);
+                pre[i] = p.x[((long)(img * p.h + cy) * p.w_ + cx) * 8 + (c & 7)];
+                okmask |= ok ? (1u << i) : 0u;
+            }
+        };
+        auto stash = [&]() {
+#pragma unroll
+            for (int i = 0; i < NPRE; ++i) {
+                const int c = min(lt + NLW * 64 * i, NCHUNK - 1);
+                const int pix = c >> 3, row = pix / HC, col = pix - row * HC;
+                const uint4 v = (okmask >> i) & 1u ? pre[i] : make_uint4(0, 0, 0, 0);
+                *(uint4*)(xl + pix * 128 + (((c & 7) ^ ((col >> 1) & 7)) << 4)) = v;
+            }
+        };
+        int tile = blockIdx.x;
+        fetch(tile);
+        stash();
+        lds_barrier();                                   // B0: weights, parameters and the first tile are in LDS
+        for (; tile < p.total; tile += gridDim.x) {
+            const int next = tile + gridDim.x;
+            if (next < p.total) fetch(next);
+            lds_barrier();                               // A: the compute waves have read the current tile
+            if (next < p.total) stash();
+            lds_barrier();                               // B: the next tile is in LDS
+        }
+        return;
+    }
+
+    // --------------------------------------------------------------------------------------------- compute waves
     int aoff[4], boff[3][4];
 #pragma unroll
     for (int s = 0; s < 4; ++s) aoff[s] = r * 128 + (((2 * s + hh) ^ ((r >> 1) & 7)) << 4);
@@ -128,52 +203,13 @@ __global__ __launch_bounds__(512, 1) void conv3x3_c64_bf16_kernel(C3Params p) {
             const int pos = r + dx;
             boff[dx][s] = pos * 128 + (((2 * s + hh) ^ ((pos >> 1) & 7)) << 4);
         }
-
-    // staging coordinates of this thread's chunks (tile-independent)
-    int srow[NPRE], scol[NPRE];
-#pragma unroll
-    for (int i = 0; i < NPRE; ++i) {
-        int c = tid + 512 * i;
-        if (c >= NCHUNK) c = NCHUNK - 1;      // duplicates the last chunk (same data, same address): harmless
-        const int pix = c >> 3;
-        srow[i] = pix / HC;
-        scol[i] = pix - srow[i] * HC;
-    }
-
-    uint4 pre[NPRE];
-    auto fetch = [&](int tile) {
-        const int txi = tile % p.tiles_x, t2 = tile / p.tiles_x, tyi = t2 % p.tiles_y, img = t2 / p.tiles_y;
-        const int y0 = tyi * TR - 1, x0 = txi * TC - 1;
-#pragma unroll
-        for (int i = 0; i < NPRE; ++i) {
-            const int gy = y0 + srow[i], gx = x0 + scol[i];
-            const bool ok = (unsigned)gy < (unsigned)p.h && (unsigned)gx < (unsigned)p.w_;
-            const int cy = min(max(gy, 0), p.h - 1), cx = min(max(gx, 0), p.w_ - 1);
-            const int chunk = min(tid + 512 * i, NCHUNK - 1) & 7;
-            uint4 v = p.x[((long)(img * p.h + cy) * p.w_ + cx) * 8 + chunk];
-            if (!ok) v = make_uint4(0, 0, 0, 0);
-            pre[i] = v;
-        }
-    };
-    auto stash = [&]() {
-#pragma unroll
-        for (int i = 0; i < NPRE; ++i) {
-            int c = tid + 512 * i;
-            if (c >= NCHUNK) c = NCHUNK - 1;
-            const int chunk = c & 7;
-            *(uint4*)(xl + (srow[i] * HC + scol[i]) * 128 + ((chunk ^ ((scol[i] >> 1) & 7)) << 4)) = pre[i];
-        }
-    };
-
-    int tile = blockIdx.x;
-    if (tile < p.total) fetch(tile);
-    stash();
-    __syncthreads();
-
     const unsigned char* xb = xl + (wv * 2) * ROWB;
-    for (; tile < p.total; tile += gridDim.x) {
-        const int next = tile + gridDim.x;
-        if (next < p.total) fetch(next);
+    lds_barrier();                                       // B0
+
+    for (int tile = blockIdx.x; tile < p.total; tile += gridDim.x) {
+        const int txi = tile % p.tiles_x, t2 = tile / p.tiles_x, tyi = t2 % p.tiles_y, img = t2 / p.tiles_y;
+        const int gx = txi * TC + r, gy0 = tyi * TR + wv * 2;
+        const bool okx = gx < p.w_;
 
         f32x16 acc[2][2];
 #pragma unroll
@@ -183,62 +219,96 @@ __global__ __launch_bounds__(512, 1) void conv3x3_c64_bf16_kernel(C3Params p) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
 
+        // 36 k-steps (9 taps x 4 channel groups of 16)
+        bf16x8 fa[2][2], fb[2][2];
+        bf16x8 rr[2][2][2];
+        auto frag = [&](int i, int buf) {
+            const int tap = i >> 2, s = i & 3, dy = tap / 3, dx = tap - 3 * dy;
+            const unsigned char* wa = wl + tap * 8192 + aoff[s];
+            fa[buf][0] = *(const bf16x8*)(wa);
+            fa[buf][1] = *(const bf16x8*)(wa + 4096);
+            fb[buf][0] = *(const bf16x8*)(xb + dy * ROWB + boff[dx][s]);
+            fb[buf][1] = *(const bf16x8*)(xb + (dy + 1) * ROWB + boff[dx][s]);
+        };
+        frag(0, 0);
 #pragma unroll
-        for (int dy = 0; dy < 3; ++dy)
+        for (int i = 0; i < 36; ++i) {
+            const int cur = i & 1;
+            if (i + 1 < 36) frag(i + 1, cur ^ 1);
+            __builtin_amdgcn_sched_barrier(0);          // keep the next step's reads ahead of this step's MFMAs
+            acc[0][0] = mfma_bf16(fa[cur][0], fb[cur][0], acc[0][0]);
+            acc[0][1] = mfma_bf16(fa[cur][0], fb[cur][1], acc[0][1]);
+            acc[1][0] = mfma_bf16(fa[cur][1], fb[cur][0], acc[1][0]);
+            acc[1][1] = mfma_bf16(fa[cur][1], fb[cur][1], acc[1][1]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (i == 27 && p.res) {
+                // the residual tile: requested under the last 8 k-steps, 16 bytes (8 channels) per lane and group
 #pragma unroll
-            for (int dx = 0; dx < 3; ++dx)
+                for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    const unsigned char* wa = wl + (dy * 3 + dx) * 8192 + aoff[s];
-                    const bf16x8 a0 = *(const bf16x8*)(wa);
-                    const bf16x8 a1 = *(const bf16x8*)(wa + 4096);
-                    const bf16x8 b0 = *(const bf16x8*)(xb + dy * ROWB + boff[dx][s]);
-                    const bf16x8 b1 = *(const bf16x8*)(xb + (dy + 1) * ROWB + boff[dx][s]);
-                    acc[0][0] = mfma_bf16(a0, b0, acc[0][0]);
-                    acc[0][1] = mfma_bf16(a0, b1, acc[0][1]);
-                    acc[1][0] = mfma_bf16(a1, b0, acc[1][0]);
-                    acc[1][1] = mfma_bf16(a1, b1, acc[1][1]);
-                }
-
-        // epilogue: y = act(acc * scale + shift) + residual, bf16, 4 consecutive channels (8 bytes) per store
-        {
-            const int txi = tile % p.tiles_x, t2 = tile / p.tiles_x, tyi = t2 % p.tiles_y, img = t2 / p.tiles_y;
-            const int gx = txi * TC + r;
+                    for (int q = 0; q < 2; ++q)
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int co = mt * 32 + 8 * g + 4 * hh;
-                    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f}, al = {p.act_alpha, p.act_alpha, p.act_alpha, p.act_alpha};
-                    if (p.scale) sc = *(const f32x4*)(p.scale + co);
-                    if (p.shift) sh = *(const f32x4*)(p.shift + co);
-                    if (p.alpha) al = *(const f32x4*)(p.alpha + co);
-#pragma unroll
-                    for (int pt = 0; pt < 2; ++pt) {
-                        const int gy = tyi * TR + wv * 2 + pt;
-                        if (gy < p.h && gx < p.w_) {
-                            const long o = ((long)(img * p.h + gy) * p.w_ + gx) * 64 + co;
-                            f32x4 v;
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) {
-                                float t = acc[mt][pt][4 * g + j] * sc[j] + sh[j];
-                                if (p.act == VCG_ACT_LRELU || p.act == VCG_ACT_PRELU) t = fmaxf(t, 0.f) + al[j] * fminf(t, 0.f);
-                                v[j] = t;
-                            }
-                            if (p.res) {
-                                const bf16x4 rr = *(const bf16x4*)(p.res + o);
-#pragma unroll
-                                for (int j = 0; j < 4; ++j) v[j] += (float)rr[j];
-                            }
-                            *(bf16x4*)(p.y + o) = __builtin_convertvector(v, bf16x4);
+                        for (int pt = 0; pt < 2; ++pt) {
+                            const int cy = min(gy0 + pt, p.h - 1), cx = min(gx, p.w_ - 1);
+                            rr[mt][q][pt] = *(const bf16x8*)(p.res + ((long)(img * p.h + cy) * p.w_ + cx) * 64 + mt * 32 + 16 * q + 8 * hh);
                         }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        lds_barrier();                                   // A: this tile's LDS image may be overwritten
+
+        // epilogue: y = act(acc * scale + shift) + residual -> bf16.  An MFMA tile leaves lane (pixel, h) with channels
+        // 8g+4h+{0..3}; v_permlane32_swap between the register groups (2q, 2q+1) of the two half-waves turns that into
+        // 8 consecutive channels 16q+8h+{0..7}: 16-byte residual loads and stores.  Phase 1 computes all final values
+        // (consuming every outstanding load), phase 2 is nothing but the 8 stores, which then drain under the next
+        // tile's MFMAs.
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int co = mt * 32 + 16 * q + 8 * hh;
+                float sc[8], sh[8], al[8];
+                *(f32x4*)&sc[0] = *(const f32x4*)(prm + co);
+                *(f32x4*)&sc[4] = *(const f32x4*)(prm + co + 4);
+                *(f32x4*)&sh[0] = *(const f32x4*)(prm + 64 + co);
+                *(f32x4*)&sh[4] = *(const f32x4*)(prm + 64 + co + 4);
+                *(f32x4*)&al[0] = *(const f32x4*)(prm + 128 + co);
+                *(f32x4*)&al[4] = *(const f32x4*)(prm + 128 + co + 4);
+#pragma unroll
+                for (int pt = 0; pt < 2; ++pt) {
+                    float v[8];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float lo = acc[mt][pt][8 * q + j], hi = acc[mt][pt][8 * q + 4 + j];
+                        swap32(lo, hi);
+                        v[j] = lo;
+                        v[4 + j] = hi;
+                    }
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        float u = v[j] * sc[j] + sh[j];
+                        u = fmaxf(u, 0.f) + al[j] * fminf(u, 0.f);           // slope 1: identity
+                        if (p.res) u += (float)rr[mt][q][pt][j];
+                        acc[mt][pt][8 * q + j] = u;
                     }
                 }
-        }
-
-        __syncthreads();
-        if (next < p.total) stash();
-        __syncthreads();
+            }
+        // pin phase 1 here (otherwise its arithmetic is sunk into the conditional store blocks, and with it the waits)
+        asm volatile("" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]));
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int pt = 0; pt < 2; ++pt) {
+                    bf16x8 ov;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) ov[j] = (__bf16)acc[mt][pt][8 * q + j];
+                    const int gy = gy0 + pt;
+                    if (gy < p.h && okx) *(bf16x8*)(p.y + ((long)(img * p.h + gy) * p.w_ + gx) * 64 + mt * 32 + 16 * q + 8 * hh) = ov;
+                }
+        lds_barrier();                                   // B: the next tile is in LDS
     }
 }
 
@@ -308,12 +378,12 @@ int vcg_conv2d_bf16_fwd(const vcg_conv_desc* d, const void* x, const void* w_pac
         p.act_alpha = ep ? ep->act_alpha : 0.f;
         static bool attr_set = false;
         if (!attr_set) {
-            hipError_t e = hipFuncSetAttribute((const void*)conv3x3_c64_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WB + XB);
+            hipError_t e = hipFuncSetAttribute((const void*)conv3x3_c64_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WB + XB + PB);
             if (e != hipSuccess) return (int)e;
             attr_set = true;
         }
         const int grid = p.total < 256 ? p.total : 256;
-        conv3x3_c64_bf16_kernel<<<grid, 512, WB + XB, stream>>>(p);
+        conv3x3_c64_bf16_kernel<<<grid, NT, WB + XB + PB, stream>>>(p);
         VCG_LAUNCH_CHECK();
         return VCG_OK;
     }
