@@ -131,6 +131,7 @@ __device__ __forceinline__ void lds_barrier() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
+template <bool AFF, bool SLOPE, bool RES>
 __global__ __launch_bounds__(NT, 1) void conv3x3_c64_bf16_kernel(C3Params p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* wl = smem;
@@ -241,7 +242,7 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_c64_bf16_kernel(C3Params p) {
             acc[1][0] = mfma_bf16(fa[cur][1], fb[cur][0], acc[1][0]);
             acc[1][1] = mfma_bf16(fa[cur][1], fb[cur][1], acc[1][1]);
             __builtin_amdgcn_sched_barrier(0);
-            if (i == 27 && p.res) {
+            if (i == 27 && RES) {
                 // the residual tile: requested under the last 8 k-steps, 16 bytes (8 channels) per lane and group
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt)
@@ -268,12 +269,16 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_c64_bf16_kernel(C3Params p) {
             for (int q = 0; q < 2; ++q) {
                 const int co = mt * 32 + 16 * q + 8 * hh;
                 float sc[8], sh[8], al[8];
-                *(f32x4*)&sc[0] = *(const f32x4*)(prm + co);
-                *(f32x4*)&sc[4] = *(const f32x4*)(prm + co + 4);
-                *(f32x4*)&sh[0] = *(const f32x4*)(prm + 64 + co);
-                *(f32x4*)&sh[4] = *(const f32x4*)(prm + 64 + co + 4);
-                *(f32x4*)&al[0] = *(const f32x4*)(prm + 128 + co);
-                *(f32x4*)&al[4] = *(const f32x4*)(prm + 128 + co + 4);
+                if (AFF) {
+                    *(f32x4*)&sc[0] = *(const f32x4*)(prm + co);
+                    *(f32x4*)&sc[4] = *(const f32x4*)(prm + co + 4);
+                    *(f32x4*)&sh[0] = *(const f32x4*)(prm + 64 + co);
+                    *(f32x4*)&sh[4] = *(const f32x4*)(prm + 64 + co + 4);
+                }
+                if (SLOPE) {
+                    *(f32x4*)&al[0] = *(const f32x4*)(prm + 128 + co);
+                    *(f32x4*)&al[4] = *(const f32x4*)(prm + 128 + co + 4);
+                }
 #pragma unroll
                 for (int pt = 0; pt < 2; ++pt) {
                     float v[8];
@@ -286,9 +291,10 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_c64_bf16_kernel(C3Params p) {
                     }
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
-                        float u = v[j] * sc[j] + sh[j];
-                        u = fmaxf(u, 0.f) + al[j] * fminf(u, 0.f);           // slope 1: identity
-                        if (p.res) u += (float)rr[mt][q][pt][j];
+                        float u = v[j];
+                        if (AFF) u = u * sc[j] + sh[j];
+                        if (SLOPE) u = u >= 0.f ? u : u * al[j];
+                        if (RES) u += (float)rr[mt][q][pt][j];
                         acc[mt][pt][8 * q + j] = u;
                     }
                 }
@@ -378,12 +384,26 @@ int vcg_conv2d_bf16_fwd(const vcg_conv_desc* d, const void* x, const void* w_pac
         p.act_alpha = ep ? ep->act_alpha : 0.f;
         static bool attr_set = false;
         if (!attr_set) {
-            hipError_t e = hipFuncSetAttribute((const void*)conv3x3_c64_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WB + XB + PB);
-            if (e != hipSuccess) return (int)e;
+            for (auto f : {(const void*)conv3x3_c64_bf16_kernel<false, false, false>, (const void*)conv3x3_c64_bf16_kernel<false, false, true>,
+                           (const void*)conv3x3_c64_bf16_kernel<false, true, false>, (const void*)conv3x3_c64_bf16_kernel<false, true, true>,
+                           (const void*)conv3x3_c64_bf16_kernel<true, false, false>, (const void*)conv3x3_c64_bf16_kernel<true, false, true>,
+                           (const void*)conv3x3_c64_bf16_kernel<true, true, false>, (const void*)conv3x3_c64_bf16_kernel<true, true, true>}) {
+                hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, WB + XB + PB);
+                if (e != hipSuccess) return (int)e;
+            }
             attr_set = true;
         }
         const int grid = p.total < 256 ? p.total : 256;
-        conv3x3_c64_bf16_kernel<<<grid, NT, WB + XB + PB, stream>>>(p);
+        const bool aff = p.scale || p.shift, slope = act != VCG_ACT_NONE, res = p.res != nullptr;
+#define VCG_C3_LAUNCH(A, S, R) conv3x3_c64_bf16_kernel<A, S, R><<<grid, NT, WB + XB + PB, stream>>>(p)
+        if (aff) {
+            if (slope) { if (res) VCG_C3_LAUNCH(true, true, true); else VCG_C3_LAUNCH(true, true, false); }
+            else { if (res) VCG_C3_LAUNCH(true, false, true); else VCG_C3_LAUNCH(true, false, false); }
+        } else {
+            if (slope) { if (res) VCG_C3_LAUNCH(false, true, true); else VCG_C3_LAUNCH(false, true, false); }
+            else { if (res) VCG_C3_LAUNCH(false, false, true); else VCG_C3_LAUNCH(false, false, false); }
+        }
+#undef VCG_C3_LAUNCH
         VCG_LAUNCH_CHECK();
         return VCG_OK;
     }
