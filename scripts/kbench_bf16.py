@@ -55,5 +55,26 @@ def main():
                  100 * nbytes / ms / 1e6 / PEAK_GBS, PEAK_GBS), flush=True)
 
 
+def bench_convt(B):
+    rt = E.Runtime.get()
+    dev = rt.device
+    h = w = 256
+    x = torch.randn(B, h, w, 64, device=dev).to(torch.bfloat16)
+    y = torch.empty(B, 2 * h, 2 * w, 256, dtype=torch.bfloat16, device=dev)
+    wk = (torch.randn(9, 256, 64, device=dev) * 0.05).to(torch.bfloat16)
+    d = L.ConvDesc(B, 64, h, w, 256, 2 * h, 2 * w, 3, 3, 2, 0, 0)
+    ep = L.EpilogueBf16(None, None, L.ACT_LRELU, 0.2, None, None)
+    flop = 2.0 * 64 * 256 * 9 * h * w * B
+    nbytes = (x.numel() + y.numel()) * 2
+
+    def run():
+        L.check(rt.lib.vcg_conv_transpose2d_bf16_fwd(ctypes.byref(d), x.data_ptr(), wk.data_ptr(), y.data_ptr(), ctypes.byref(ep), rt.stream), "convT")
+    ms = timeit(run)
+    print("%-28s B=%d  %.3f ms  %7.1f TFLOP/s (%.1f%% of %.0f)  %6.0f GB/s algorithmic (%.1f%% of %.0f)"
+          % ("convT 3x3 s2 64->256 +LReLU", B, ms, flop / ms / 1e9, 100 * flop / ms / 1e9 / PEAK_TF, PEAK_TF, nbytes / ms / 1e6,
+             100 * nbytes / ms / 1e6 / PEAK_GBS, PEAK_GBS), flush=True)
+
+
 if __name__ == "__main__":
     main()
+    bench_convt(int(sys.argv[1]) if len(sys.argv) > 1 else 32)

@@ -117,3 +117,39 @@ def test_conv3x3_c64_bf16(rt, n, h, w, affine, act, residual):
     report("bf16 conv3x3 c64 n=%d %dx%d affine=%s act=%s res=%s  err=%.2e  elementwise(ulp-scaled)=%.2f" % (n, h, w, affine, act, residual, e, ew))
     assert e < TOL_BF16
     assert ew < 1.0
+
+
+CT_CASES = [
+    # n, h, w, cout, lrelu
+    (2, 12, 32, 64, False),
+    (1, 13, 45, 128, True),         # ragged tile edges
+    (2, 40, 72, 256, True),         # upsampling_block(64 -> 256)
+    (1, 5, 7, 256, True),
+]
+
+
+@pytest.mark.parametrize("n,h,w,cout,lrelu", CT_CASES)
+def test_conv_transpose3x3_s2_bf16(rt, n, h, w, cout, lrelu):
+    from oracle import keras_ops as K
+    from upscaler import _lib as L
+    g = torch.Generator().manual_seed(n * 1000 + h * 10 + w + cout)
+    x = torch.randn(n, 64, h, w, generator=g)
+    wk = torch.randn(3, 3, cout, 64, generator=g) * 0.06          # Keras Conv2DTranspose (kh,kw,out,in)
+    xd = _to_nhwc_bf16(rt, x.to(rt.device))
+    wd = wk.to(rt.device)
+    wp = torch.empty(9, cout, 64, dtype=torch.bfloat16, device=rt.device)
+    L.check(rt.lib.vcg_pack_conv_kernel_bf16(wd.data_ptr(), 9, cout, 64, 0, 0, wp.data_ptr(), rt.stream), "pack")
+    y = torch.empty(n, 2 * h, 2 * w, cout, dtype=torch.bfloat16, device=rt.device)
+    d = L.ConvDesc(n, 64, h, w, cout, 2 * h, 2 * w, 3, 3, 2, 0, 0)
+    ep = L.EpilogueBf16(None, None, L.ACT_LRELU if lrelu else L.ACT_NONE, 0.2, None, None)
+    L.check(rt.lib.vcg_conv_transpose2d_bf16_fwd(ctypes.byref(d), xd.data_ptr(), wp.data_ptr(), y.data_ptr(), ctypes.byref(ep), rt.stream),
+            "vcg_conv_transpose2d_bf16_fwd")
+    got = _to_nchw_f32(rt, y).cpu().double()
+    ref = K.conv2d_transpose_same(_bf16_round(x), _bf16_round(wk), None, 2)
+    if lrelu:
+        ref = torch.where(ref >= 0, ref, 0.2 * ref)
+    e = rel_err(got, ref)
+    ew = float(((got - ref).abs() / (ref.abs() * 2.0 ** -8 + 1e-3 * ref.abs().max())).max())
+    report("bf16 convT3x3 s2 64->%d n=%d %dx%d lrelu=%s  err=%.2e  elementwise(ulp-scaled)=%.2f" % (cout, n, h, w, lrelu, e, ew))
+    assert e < TOL_BF16
+    assert ew < 1.0

@@ -9,6 +9,7 @@
 // with the inference-mode BatchNormalization folded into a per-channel scale/shift (model.py:20,23,284),
 // PReLU (model.py:21) and the block's Add (model.py:25,285) fused into the epilogue.
 #include "vcg_common.hpp"
+#include <utility>
 
 namespace {
 
@@ -318,6 +319,184 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_c64_bf16_kernel(C3Params p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// 3x3 stride-2 'same' transposed convolution, 64 -> 64*m channels (+LeakyReLU): upsampling_block (model.py:70-75)
+// ---------------------------------------------------------------------------------------------------------------
+// TF 'same' with k=3, s=2 crops nothing at the top/left: out[o] = sum_i x[i] w[o-2i]  =>  the four sub-pixel phases
+//   even output rows (2q):   taps ky=0 (input row q) and ky=2 (input row q-1);   odd rows (2q+1): ky=1 (row q)
+// and the same along x: 4 + 2 + 2 + 1 = 9 taps, the same 36 k-steps per 64x64 wave tile as the 3x3 convolution, but
+// four accumulator tiles' worth of output.  Same organisation as conv3x3_c64_bf16_kernel: persistent workgroups of
+// 6 compute + 2 loader waves, weights of ONE 64-channel output block resident in LDS (blockIdx & (m-1) picks the
+// block, so the grid is a multiple of m), input halo tile = 1 row above / 1 column left of 12x32 input pixels.
+constexpr int TH = TR + 1;                   // halo rows of the transposed convolution (row -1 .. TR-1)
+constexpr int TXB = TH * ROWB;               // 13 rows x 34 columns (column 33 unused) x 128 B
+constexpr int TNCHUNK = TH * HC * 8;
+constexpr int TNPRE = (TNCHUNK + NLW * 64 - 1) / (NLW * 64);
+
+struct CTParams {
+    const uint4* x;
+    const uint4* w;          // packed [9][cout][64]
+    __bf16* y;
+    int n, h, w_, cout, tiles_x, tiles_y, total;    // total = n * tiles_y * tiles_x (per output-channel block)
+    float slope;             // LeakyReLU slope (1 = none)
+};
+
+// k-step tables (compile time): phase-major tap order; ky*3+kx and the halo row / column offset of the tap
+// (1 = same input pixel, 0 = the previous one); taps [0,4) -> phase (0,0), [4,6) -> (0,1), [6,8) -> (1,0), 8 -> (1,1)
+__host__ __device__ constexpr int ct_tap(int t) { constexpr int T[9] = {0, 2, 6, 8, 1, 7, 3, 5, 4}; return T[t]; }
+__host__ __device__ constexpr int ct_rdy(int t) { constexpr int T[9] = {1, 1, 0, 0, 1, 0, 1, 1, 1}; return T[t]; }
+__host__ __device__ constexpr int ct_rdx(int t) { constexpr int T[9] = {1, 0, 1, 0, 1, 1, 1, 0, 1}; return T[t]; }
+__host__ __device__ constexpr int ct_phase(int t) { return t < 4 ? 0 : t < 6 ? 1 : t < 8 ? 2 : 3; }
+__host__ __device__ constexpr bool ct_first(int t) { return t == 0 || t == 4 || t == 6 || t == 8; }
+__host__ __device__ constexpr bool ct_last(int t) { return t == 3 || t == 5 || t == 7 || t == 8; }
+
+template <class F, int... Is>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Is...>) {
+    (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+__global__ __launch_bounds__(NT, 1) void convt3x3_c64_bf16_kernel(CTParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* wl = smem;
+    unsigned char* xl = smem + WB;
+    const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, hh = lane >> 5;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nblk = p.cout >> 6, cb = blockIdx.x % nblk, wg = blockIdx.x / nblk, nwg = gridDim.x / nblk;
+
+    for (int c = tid; c < 9 * 64 * 8; c += NT) {
+        const int chunk = c & 7, co = (c >> 3) & 63, tap = c >> 9;
+        *(uint4*)(wl + tap * 8192 + co * 128 + ((chunk ^ ((co >> 1) & 7)) << 4)) = p.w[((long)tap * p.cout + cb * 64 + co) * 8 + chunk];
+    }
+
+    if (wv >= NCW) {
+        const int lt = tid - NCW * 64;
+        uint4 pre[TNPRE];
+        unsigned okmask = 0;
+        auto fetch = [&](int tile) {
+            const int txi = tile % p.tiles_x, t2 = tile / p.tiles_x, tyi = t2 % p.tiles_y, img = t2 / p.tiles_y;
+            const int y0 = tyi * TR - 1, x0 = txi * TC - 1;
+            okmask = 0;
+#pragma unroll
+            for (int i = 0; i < TNPRE; ++i) {
+                const int c = min(lt + NLW * 64 * i, TNCHUNK - 1);
+                const int pix = c >> 3, row = pix / HC, col = pix - row * HC;
+                const int gy = y0 + row, gx = x0 + col;
+                const bool ok = (unsigned)gy < (unsigned)p.h && (unsigned)gx < (unsigned)p.w_;
+                const int cy = min(max(gy, 0), p.h - 1), cx = min(max(gx, 0), p.w_ - 1);
+                pre[i] = p.x[((long)(img * p.h + cy) * p.w_ + cx) * 8 + (c & 7)];
+                okmask |= ok ? (1u << i) : 0u;
+            }
+        };
+        auto stash = [&]() {
+#pragma unroll
+            for (int i = 0; i < TNPRE; ++i) {
+                const int c = min(lt + NLW * 64 * i, TNCHUNK - 1);
+                const int pix = c >> 3, row = pix / HC, col = pix - row * HC;
+                const uint4 v = (okmask >> i) & 1u ? pre[i] : make_uint4(0, 0, 0, 0);
+                *(uint4*)(xl + pix * 128 + (((c & 7) ^ ((col >> 1) & 7)) << 4)) = v;
+            }
+        };
+        int tile = wg;
+        if (tile < p.total) fetch(tile);
+        stash();
+        lds_barrier();
+        for (; tile < p.total; tile += nwg) {
+            const int next = tile + nwg;
+            if (next < p.total) fetch(next);
+            lds_barrier();
+            if (next < p.total) stash();
+            lds_barrier();
+        }
+        return;
+    }
+
+    int aoff[4], boff[2][4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) aoff[s] = r * 128 + (((2 * s + hh) ^ ((r >> 1) & 7)) << 4);
+#pragma unroll
+    for (int dx = 0; dx < 2; ++dx)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int pos = r + dx;
+            boff[dx][s] = pos * 128 + (((2 * s + hh) ^ ((pos >> 1) & 7)) << 4);
+        }
+    const unsigned char* xb = xl + (wv * 2) * ROWB;
+    const int ow = 2 * p.w_, oh = 2 * p.h;
+    lds_barrier();
+
+    for (int tile = wg; tile < p.total; tile += nwg) {
+        const int txi = tile % p.tiles_x, t2 = tile / p.tiles_x, tyi = t2 % p.tiles_y, img = t2 / p.tiles_y;
+        const int gx = txi * TC + r, gy0 = tyi * TR + wv * 2;
+        const bool okx = gx < p.w_;
+
+        f32x16 acc[2][2];
+        bf16x8 fa[2][2], fb[2][2];
+        auto frag = [&](auto ic) {
+            constexpr int i = decltype(ic)::value, t = i >> 2, s = i & 3, buf = i & 1;
+            const unsigned char* wa = wl + ct_tap(t) * 8192 + aoff[s];
+            fa[buf][0] = *(const bf16x8*)(wa);
+            fa[buf][1] = *(const bf16x8*)(wa + 4096);
+            fb[buf][0] = *(const bf16x8*)(xb + ct_rdy(t) * ROWB + boff[ct_rdx(t)][s]);
+            fb[buf][1] = *(const bf16x8*)(xb + (ct_rdy(t) + 1) * ROWB + boff[ct_rdx(t)][s]);
+        };
+        frag(std::integral_constant<int, 0>{});
+        static_for<36>([&](auto ic) {
+            constexpr int i = decltype(ic)::value, cur = i & 1, t = i >> 2;
+            constexpr bool first = (i & 3) == 0 && ct_first(t), last = (i & 3) == 3 && ct_last(t);
+            if constexpr (i + 1 < 36) frag(std::integral_constant<int, i + 1>{});
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (first) {
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+            }
+            acc[0][0] = mfma_bf16(fa[cur][0], fb[cur][0], acc[0][0]);
+            acc[0][1] = mfma_bf16(fa[cur][0], fb[cur][1], acc[0][1]);
+            acc[1][0] = mfma_bf16(fa[cur][1], fb[cur][0], acc[1][0]);
+            acc[1][1] = mfma_bf16(fa[cur][1], fb[cur][1], acc[1][1]);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (last) {
+                // this phase's 64 channels x 64 output pixels: LeakyReLU, bf16, 16-byte stores
+                constexpr int py = ct_phase(t) >> 1, px = ct_phase(t) & 1;
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int q = 0; q < 2; ++q)
+#pragma unroll
+                        for (int pt = 0; pt < 2; ++pt) {
+                            float v[8];
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                float lo = acc[mt][pt][8 * q + j], hi = acc[mt][pt][8 * q + 4 + j];
+                                swap32(lo, hi);
+                                v[j] = lo;
+                                v[4 + j] = hi;
+                            }
+                            bf16x8 ov;
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) {
+                                const float u = v[j] >= 0.f ? v[j] : v[j] * p.slope;
+                                ov[j] = (__bf16)u;
+                            }
+                            const int gy = gy0 + pt;
+                            if (gy < p.h && okx)
+                                *(bf16x8*)(p.y + ((long)(img * oh + 2 * gy + py) * ow + 2 * gx + px) * p.cout + cb * 64 + mt * 32 + 16 * q + 8 * hh) = ov;
+                        }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        });
+        lds_barrier();
+        lds_barrier();
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -408,6 +587,44 @@ int vcg_conv2d_bf16_fwd(const vcg_conv_desc* d, const void* x, const void* w_pac
         return VCG_OK;
     }
     return VCG_E_UNSUPPORTED;
+}
+
+int vcg_conv_transpose2d_bf16_fwd(const vcg_conv_desc* d, const void* x, const void* w_packed, void* y, const vcg_epilogue_bf16* ep,
+                                  hipStream_t stream) {
+    VCG_CHECK_PTR(d);
+    VCG_CHECK_PTR(x);
+    VCG_CHECK_PTR(w_packed);
+    VCG_CHECK_PTR(y);
+    if (d->n <= 0 || d->h <= 0 || d->w <= 0) return VCG_E_SHAPE;
+    if (d->oh != 2 * d->h || d->ow != 2 * d->w || d->stride != 2) return VCG_E_SHAPE;
+    const int act = ep ? ep->act : VCG_ACT_NONE;
+    if (ep && (ep->scale || ep->shift || ep->residual)) return VCG_E_UNSUPPORTED;
+    if (act != VCG_ACT_NONE && act != VCG_ACT_LRELU) return VCG_E_UNSUPPORTED;
+    const int nblk = d->cout / 64;
+    if (d->cin != 64 || d->cout % 64 != 0 || (nblk & (nblk - 1)) != 0 || nblk > 8 || d->kh != 3 || d->kw != 3) return VCG_E_UNSUPPORTED;
+    CTParams p;
+    p.x = (const uint4*)x;
+    p.w = (const uint4*)w_packed;
+    p.y = (__bf16*)y;
+    p.n = d->n;
+    p.h = d->h;
+    p.w_ = d->w;
+    p.cout = d->cout;
+    p.tiles_x = ceil_div(d->w, TC);
+    p.tiles_y = ceil_div(d->h, TR);
+    p.total = p.n * p.tiles_x * p.tiles_y;
+    p.slope = act == VCG_ACT_LRELU ? ep->act_alpha : 1.f;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)convt3x3_c64_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WB + TXB);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    int per = 256 / nblk;                       // workgroups per output-channel block
+    if (per > p.total) per = p.total;
+    convt3x3_c64_bf16_kernel<<<per * nblk, NT, WB + TXB, stream>>>(p);
+    VCG_LAUNCH_CHECK();
+    return VCG_OK;
 }
 
 }  // extern "C"

@@ -78,6 +78,7 @@ SIGNATURES = {
     "vcg_f32_nchw_to_bf16_nhwc": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
     "vcg_bf16_nhwc_to_f32_nchw": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
     "vcg_conv2d_bf16_fwd": (c_int, [_D, _P, _P, _P, _EB, _P]),
+    "vcg_conv_transpose2d_bf16_fwd": (c_int, [_D, _P, _P, _P, _EB, _P]),
 }
 
 _lib = None
