@@ -211,6 +211,15 @@ int vcg_conv2d_bf16_fwd(const vcg_conv_desc* d, const void* x, const void* w_pac
 int vcg_conv_transpose2d_bf16_fwd(const vcg_conv_desc* d, const void* x, const void* w_packed, void* y, const vcg_epilogue_bf16* ep,
                                   hipStream_t stream);
 
+/* final/conv of the generator (upscaling/upscaler/model.py:290-291): Conv2D(3, 9, 'same') + bias + tanh on a bf16 NHWC
+ * input with 256 channels; output fp32 NCHW (what vcg_nchw_to_frames_u8 consumes).  wfrag: the kernel re-laid out as
+ * MFMA operand fragments by vcg_pack_final9x9_bf16 from Keras' (9,9,256,3) fp32 kernel: VCG_FINAL9X9_WFRAG_BYTES bytes
+ * (9216 fragments of 16 bytes + 64 zero bytes the kernel fetches its padding pixels from). */
+#define VCG_FINAL9X9_WFRAG_BYTES ((4 * 9 * 4 * 64 + 4) * 16)
+int vcg_pack_final9x9_bf16(const void* w, void* out, hipStream_t stream);
+int vcg_conv9x9_to3_bf16_fwd(const vcg_conv_desc* d, const void* x, const void* wfrag, const void* bias, int32_t tanh_act, void* y,
+                             hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

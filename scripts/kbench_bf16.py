@@ -75,6 +75,29 @@ def bench_convt(B):
              100 * nbytes / ms / 1e6 / PEAK_GBS, PEAK_GBS), flush=True)
 
 
+def bench_final(B):
+    rt = E.Runtime.get()
+    dev = rt.device
+    h = w = 512
+    x = torch.randn(B, h, w, 256, device=dev).to(torch.bfloat16)
+    y = torch.empty(B, 3, h, w, dtype=torch.float32, device=dev)
+    wk = torch.randn(9, 9, 256, 3, device=dev) * 0.01
+    wf = torch.empty(L.FINAL9X9_WFRAG_BYTES, dtype=torch.uint8, device=dev)
+    L.check(rt.lib.vcg_pack_final9x9_bf16(wk.data_ptr(), wf.data_ptr(), rt.stream), "pack9")
+    bias = torch.zeros(3, device=dev)
+    d = L.ConvDesc(B, 256, h, w, 3, h, w, 9, 9, 1, 4, 4)
+    flop = 2.0 * 256 * 3 * 81 * h * w * B
+    nbytes = x.numel() * 2 + y.numel() * 4
+
+    def run():
+        L.check(rt.lib.vcg_conv9x9_to3_bf16_fwd(ctypes.byref(d), x.data_ptr(), wf.data_ptr(), bias.data_ptr(), 1, y.data_ptr(), rt.stream), "final")
+    ms = timeit(run)
+    print("%-28s B=%d  %.3f ms  %7.1f TFLOP/s useful (%.1f%% of %.0f)  %6.0f GB/s algorithmic (%.1f%% of %.0f)"
+          % ("final 9x9 256->3 +tanh", B, ms, flop / ms / 1e9, 100 * flop / ms / 1e9 / PEAK_TF, PEAK_TF, nbytes / ms / 1e6,
+             100 * nbytes / ms / 1e6 / PEAK_GBS, PEAK_GBS), flush=True)
+
+
 if __name__ == "__main__":
     main()
     bench_convt(int(sys.argv[1]) if len(sys.argv) > 1 else 32)
+    bench_final(int(sys.argv[1]) if len(sys.argv) > 1 else 32)

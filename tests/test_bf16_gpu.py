@@ -153,3 +153,36 @@ def test_conv_transpose3x3_s2_bf16(rt, n, h, w, cout, lrelu):
     report("bf16 convT3x3 s2 64->%d n=%d %dx%d lrelu=%s  err=%.2e  elementwise(ulp-scaled)=%.2f" % (cout, n, h, w, lrelu, e, ew))
     assert e < TOL_BF16
     assert ew < 1.0
+
+
+F9_CASES = [
+    # n, h, w, tanh
+    (1, 20, 64, True),
+    (2, 37, 70, True),            # two strips (ragged), rows not a multiple of anything
+    (1, 140, 40, False),          # two row segments
+    (1, 6, 9, True),
+]
+
+
+@pytest.mark.parametrize("n,h,w,tanh", F9_CASES)
+def test_final_conv9x9_256to3_bf16(rt, n, h, w, tanh):
+    from oracle import keras_ops as K
+    from upscaler import _lib as L
+    g = torch.Generator().manual_seed(n * 1000 + h * 10 + w)
+    x = torch.randn(n, 256, h, w, generator=g)
+    wk = torch.randn(9, 9, 256, 3, generator=g) * 0.01
+    b = torch.randn(3, generator=g) * 0.1
+    xd = _to_nhwc_bf16(rt, x.to(rt.device))
+    wd, bd = wk.to(rt.device), b.to(rt.device)
+    wf = torch.empty(L.FINAL9X9_WFRAG_BYTES, dtype=torch.uint8, device=rt.device)
+    L.check(rt.lib.vcg_pack_final9x9_bf16(wd.data_ptr(), wf.data_ptr(), rt.stream), "pack9")
+    y = torch.empty(n, 3, h, w, dtype=torch.float32, device=rt.device)
+    d = L.ConvDesc(n, 256, h, w, 3, h, w, 9, 9, 1, 4, 4)
+    L.check(rt.lib.vcg_conv9x9_to3_bf16_fwd(ctypes.byref(d), xd.data_ptr(), wf.data_ptr(), bd.data_ptr(), 1 if tanh else 0, y.data_ptr(), rt.stream),
+            "vcg_conv9x9_to3_bf16_fwd")
+    ref = K.conv2d(_bf16_round(x), _bf16_round(wk), b.double(), 1, "same")
+    if tanh:
+        ref = torch.tanh(ref)
+    e = rel_err(y.cpu().double(), ref)
+    report("bf16 final conv9x9 256->3 n=%d %dx%d tanh=%s  err=%.2e (fp32 output)" % (n, h, w, tanh, e))
+    assert e < 1e-4          # bf16 operands are exact in both; only the fp32 accumulation order differs

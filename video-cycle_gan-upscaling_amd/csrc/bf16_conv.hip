@@ -497,6 +497,189 @@ __global__ __launch_bounds__(NT, 1) void convt3x3_c64_bf16_kernel(CTParams p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// 9x9 stride-1 'same' convolution, 256 -> 3 channels (+bias, tanh): the generator's final/conv (model.py:290-291)
+// ---------------------------------------------------------------------------------------------------------------
+// Three output channels would waste 29 of the MFMA's 32 rows, so the rows carry (ky, co) instead:
+//   row 4*ky+co (ky < 8)  and  row 4*co+3 (ky = 8);      k = (kx, ci);      columns = 32 consecutive x.
+// One MFMA pass over ONE input row yi then yields, for every ky, that row's contribution to output row yi+4-ky.
+// A wave marches down the image and carries the partial sums of the 9 output rows in flight IN THE ACCUMULATOR:
+// before the next input row the accumulator is shifted by one ky-group (4 rows = half a register group: a
+// v_permlane32_swap + select per register) and handed to the MFMA as its C operand; the group that falls off the end
+// (ky = 7) lands in the spare rows 3,7,11, where the ky = 8 products complete it.  After the pass those three rows
+// hold the finished output row yi-4 -- no atomics, no partial tensors, every input row is read from HBM once.
+//   * the 256 input channels are split over the 4 waves of a workgroup (64 each): the 9x4 weight fragments of a
+//     wave stay in 144 VGPRs; the four partial output rows meet in LDS once per row (768 B per wave);
+//   * the wave's 72-pixel x 64-channel slice of the input row goes HBM -> LDS by global_load_lds (no VGPRs), double
+//     buffered, XOR-swizzled on the global side so that the shifted ds_read_b128 of all 9 kx are conflict-free;
+//   * work item = (image, 64-column strip, segment of F_SH output rows); 2 workgroups per CU.
+constexpr int F_SH = 128;                    // output rows per work item (8 halo rows are recomputed per segment)
+constexpr int F_PIX = 72;                    // 64 output columns + 4 + 4
+constexpr int F_ROWB = F_PIX * 128;          // one wave's slice of one input row in LDS (9216 B)
+constexpr int F_LDS = 4 * 2 * F_ROWB + 2 * 4 * 3 * 64 * 4;
+constexpr int F_NFRAG = 4 * 9 * 4 * 64;      // 16-byte weight fragments; the packed buffer holds 4 more (zeros)
+
+struct F9Params {
+    const unsigned char* x;      // bf16 NHWC [n][h][w][256]
+    const uint4* wfrag;          // packed [4 chunks][9 kx][4 s][64 lanes] x 16 B, followed by 64 zero bytes
+    const float* bias;           // [3] or null
+    float* y;                    // fp32 NCHW [n][3][h][w]
+    int n, h, w_, strips, segs, total;
+    int tanh_act;
+};
+
+__global__ __launch_bounds__(256, 2) void conv9x9_c256to3_bf16_kernel(F9Params p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, hh = lane >> 5;
+    const int c = __builtin_amdgcn_readfirstlane(tid >> 6);          // wave = input-channel chunk
+    unsigned char* rowbuf = smem + c * 2 * F_ROWB;
+    float* part = (float*)(smem + 4 * 2 * F_ROWB);                    // [2][4][3][64]
+
+    // weights: 36 fragments of 16 B per lane
+    bf16x8 wf[9][4];
+#pragma unroll
+    for (int kx = 0; kx < 9; ++kx)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const uint4 v = p.wfrag[((c * 9 + kx) * 4 + s) * 64 + lane];
+            wf[kx][s] = __builtin_bit_cast(bf16x8, v);
+        }
+    // B-fragment addresses: pixel (r+kx) of the slice, chunk (2s+h) ^ f(pixel);  addr = T[kx] ^ (s << 5)
+    int T[9];
+#pragma unroll
+    for (int kx = 0; kx < 9; ++kx) {
+        const int pos = r + kx;
+        T[kx] = (pos * 128) | ((((pos >> 1) & 7) ^ hh) << 4);
+    }
+    // DMA slots of this lane: slot = k*64 + lane -> pixel = slot >> 3, stored chunk = slot & 7 holds channel chunk
+    // (slot & 7) ^ f(pixel)
+    // (recomputed per row from three lane constants: 18 more live VGPRs would spill)
+    const int l3 = lane >> 3, l4 = lane >> 4, l7 = lane & 7;
+    const float bias = (p.bias && tid < 192) ? p.bias[tid >> 6] : 0.f;
+    const unsigned char* zeros = (const unsigned char*)(p.wfrag + F_NFRAG);      // padding pixels are fetched from here
+
+    for (int item = blockIdx.x; item < p.total; item += gridDim.x) {
+        const int seg = item % p.segs, i2 = item / p.segs, strip = i2 % p.strips, img = i2 / p.strips;
+        const int x0 = strip * 64, y0 = seg * F_SH, y1 = min(y0 + F_SH, p.h);
+
+        auto dma = [&](int yi, int buf) {
+            const bool rowok = (unsigned)yi < (unsigned)p.h;
+            const unsigned char* rowp = p.x + ((long)(img * p.h + (rowok ? yi : 0)) * p.w_) * 512;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                const int gx = x0 - 4 + k * 8 + l3;
+                const bool ok = rowok && (unsigned)gx < (unsigned)p.w_;
+                const int dsrc = (c * 8 + (l7 ^ ((4 * k + l4) & 7))) * 16;
+                const unsigned char* src = ok ? rowp + (long)gx * 512 + dsrc : zeros;
+                __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src,
+                                                 (void __attribute__((address_space(3)))*)(rowbuf + buf * F_ROWB + k * 1024), 16, 0, 0);
+            }
+        };
+
+        f32x16 acc[2];
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[tt][e] = 0.f;
+
+        dma(y0 - 4, 0);
+        for (int yi = y0 - 4; yi < y1 + 4; ++yi) {
+            const int buf = (yi - (y0 - 4)) & 1;
+            __builtin_amdgcn_s_waitcnt(0x0F70);              // vmcnt(0): this row's slice has landed in LDS
+            asm volatile("" ::: "memory");
+            if (yi + 1 < y1 + 4) dma(yi + 1, buf ^ 1);
+            const unsigned char* xb = rowbuf + buf * F_ROWB;
+
+            // shift the partial sums by one ky group and use them as the C operand
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) {
+                float lo[16], hi[16];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    float a = acc[tt][j], b = acc[tt][j];
+                    swap32(a, b);                            // a = (lower, lower), b = (upper, upper)
+                    lo[j] = a;
+                    hi[j] = b;
+                }
+#pragma unroll
+                for (int jq = 0; jq < 4; ++jq)
+#pragma unroll
+                    for (int sl = 0; sl < 3; ++sl) {
+                        const float from_prev = jq > 0 ? hi[4 * (jq - 1) + sl] : 0.f;       // group 2jq-1 -> 2jq
+                        acc[tt][4 * jq + sl] = hh ? lo[4 * jq + sl] : from_prev;            // group 2jq -> 2jq+1
+                    }
+                acc[tt][3] = hh ? hi[13] : hi[12];           // rows 3 / 7  <- group 7, co 0 / 1
+                acc[tt][7] = hh ? 0.f : hi[14];              // row 11      <- group 7, co 2
+                acc[tt][11] = 0.f;
+                acc[tt][15] = 0.f;
+            }
+
+            bf16x8 fb[2][2];
+            auto frag = [&](auto ic) {
+                constexpr int i = decltype(ic)::value, kx = i >> 2, s = i & 3, bq = i & 1;
+                const unsigned char* a = xb + (T[kx] ^ (s << 5));
+                fb[bq][0] = *(const bf16x8*)(a);
+                fb[bq][1] = *(const bf16x8*)(a + 32 * 128);
+            };
+            frag(std::integral_constant<int, 0>{});
+            static_for<36>([&](auto ic) {
+                constexpr int i = decltype(ic)::value, kx = i >> 2, s = i & 3, cur = i & 1;
+                if constexpr (i + 1 < 36) frag(std::integral_constant<int, i + 1>{});
+                __builtin_amdgcn_sched_barrier(0);
+                acc[0] = mfma_bf16(wf[kx][s], fb[cur][0], acc[0]);
+                acc[1] = mfma_bf16(wf[kx][s], fb[cur][1], acc[1]);
+                __builtin_amdgcn_sched_barrier(0);
+            });
+
+            // finished output row yo = yi - 4: this wave's partial (its 64 input channels) -> LDS
+            const int yo = yi - 4, slot = yo & 1;
+            if (yo >= y0) {
+                float* pp = part + ((slot * 4 + c) * 3) * 64;
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt) {
+                    if (hh == 0) {
+                        pp[0 * 64 + tt * 32 + r] = acc[tt][3];
+                        pp[2 * 64 + tt * 32 + r] = acc[tt][7];
+                    } else {
+                        pp[1 * 64 + tt * 32 + r] = acc[tt][3];
+                    }
+                }
+            }
+            lds_barrier();
+            if (yo >= y0 && tid < 192) {
+                const int co = tid >> 6, col = tid & 63;
+                const float* q = part + slot * 4 * 3 * 64 + co * 64 + col;
+                float v = ((q[0] + q[3 * 64]) + (q[2 * 3 * 64] + q[3 * 3 * 64])) + bias;
+                if (p.tanh_act) v = tanhf(v);
+                if (x0 + col < p.w_) p.y[((long)(img * 3 + co) * p.h + yo) * p.w_ + x0 + col] = v;
+            }
+        }
+        lds_barrier();       // the next item's first partial slot / row buffers are free
+    }
+}
+
+__global__ void pack_final9x9_kernel(const float* __restrict__ w, uint4* __restrict__ out) {
+    // w: Keras (9,9,256,3) -> out[chunk][kx][s][lane] = 8 bf16: A[row = lane&31][k = 8*(lane>>5) + j] of k-step (kx, s)
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= F_NFRAG + 4) return;
+    if (idx >= F_NFRAG) {
+        out[idx] = make_uint4(0, 0, 0, 0);
+        return;
+    }
+    const int lane = idx & 63, s = (idx >> 6) & 3, kx = (idx >> 8) % 9, c = idx / (9 * 256);
+    const int row = lane & 31, h = lane >> 5, g = row >> 2, sl = row & 3;
+    int ky = -1, co = 0;
+    if (sl < 3) { ky = g; co = sl; }
+    else if (g < 3) { ky = 8; co = g; }
+    bf16x8 v;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int ci = c * 64 + 16 * s + 8 * h + j;
+        v[j] = (__bf16)(ky >= 0 ? w[((ky * 9 + kx) * 256 + ci) * 3 + co] : 0.f);
+    }
+    out[idx] = __builtin_bit_cast(uint4, v);
+}
+
 }  // namespace
 
 extern "C" {
@@ -623,6 +806,46 @@ int vcg_conv_transpose2d_bf16_fwd(const vcg_conv_desc* d, const void* x, const v
     int per = 256 / nblk;                       // workgroups per output-channel block
     if (per > p.total) per = p.total;
     convt3x3_c64_bf16_kernel<<<per * nblk, NT, WB + TXB, stream>>>(p);
+    VCG_LAUNCH_CHECK();
+    return VCG_OK;
+}
+
+int vcg_pack_final9x9_bf16(const void* w, void* out, hipStream_t stream) {
+    VCG_CHECK_PTR(w);
+    VCG_CHECK_PTR(out);
+    pack_final9x9_kernel<<<(F_NFRAG + 4 + 255) / 256, 256, 0, stream>>>((const float*)w, (uint4*)out);
+    VCG_LAUNCH_CHECK();
+    return VCG_OK;
+}
+
+int vcg_conv9x9_to3_bf16_fwd(const vcg_conv_desc* d, const void* x, const void* wfrag, const void* bias, int32_t tanh_act, void* y,
+                             hipStream_t stream) {
+    VCG_CHECK_PTR(d);
+    VCG_CHECK_PTR(x);
+    VCG_CHECK_PTR(wfrag);
+    VCG_CHECK_PTR(y);
+    if (d->n <= 0 || d->h <= 0 || d->w <= 0 || d->oh != d->h || d->ow != d->w) return VCG_E_SHAPE;
+    if (d->cin != 256 || d->cout != 3 || d->kh != 9 || d->kw != 9 || d->stride != 1 || d->pad_top != 4 || d->pad_left != 4) return VCG_E_UNSUPPORTED;
+    F9Params p;
+    p.x = (const unsigned char*)x;
+    p.wfrag = (const uint4*)wfrag;
+    p.bias = (const float*)bias;
+    p.y = (float*)y;
+    p.n = d->n;
+    p.h = d->h;
+    p.w_ = d->w;
+    p.strips = ceil_div(d->w, 64);
+    p.segs = ceil_div(d->h, F_SH);
+    p.total = p.n * p.strips * p.segs;
+    p.tanh_act = tanh_act;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)conv9x9_c256to3_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    const int grid = p.total < 512 ? p.total : 512;
+    conv9x9_c256to3_bf16_kernel<<<grid, 256, F_LDS, stream>>>(p);
     VCG_LAUNCH_CHECK();
     return VCG_OK;
 }
