@@ -207,7 +207,7 @@ int vcg_conv2d_bf16_fwd(const vcg_conv_desc* d, const void* x, const void* w_pac
 
 /* Conv2DTranspose(strides=2, padding='same') forward on bf16 NHWC (+ fused LeakyReLU: upsampling_block,
  * upscaling/upscaler/model.py:70-75).  w_packed: [tap][out][in] (vcg_pack_conv_kernel_bf16(w, 9, out, in, 0, 0) from
- * Keras' (kh,kw,out,in)).  Instantiated: 3x3, in = 64, out = 64 * {1,2,4,8}; ep may carry VCG_ACT_LRELU only. */
+ * Keras' (kh,kw,out,in)).  Instantiated: 3x3, in = 64, out = 64 * {1,2,4,8}; ep may carry shift (the bias) and VCG_ACT_LRELU. */
 int vcg_conv_transpose2d_bf16_fwd(const vcg_conv_desc* d, const void* x, const void* w_packed, void* y, const vcg_epilogue_bf16* ep,
                                   hipStream_t stream);
 

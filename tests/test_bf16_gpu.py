@@ -141,11 +141,13 @@ def test_conv_transpose3x3_s2_bf16(rt, n, h, w, cout, lrelu):
     L.check(rt.lib.vcg_pack_conv_kernel_bf16(wd.data_ptr(), 9, cout, 64, 0, 0, wp.data_ptr(), rt.stream), "pack")
     y = torch.empty(n, 2 * h, 2 * w, cout, dtype=torch.bfloat16, device=rt.device)
     d = L.ConvDesc(n, 64, h, w, cout, 2 * h, 2 * w, 3, 3, 2, 0, 0)
-    ep = L.EpilogueBf16(None, None, L.ACT_LRELU if lrelu else L.ACT_NONE, 0.2, None, None)
+    bias = torch.randn(cout, generator=g) * 0.3
+    bd = bias.to(rt.device)
+    ep = L.EpilogueBf16(None, bd.data_ptr(), L.ACT_LRELU if lrelu else L.ACT_NONE, 0.2, None, None)
     L.check(rt.lib.vcg_conv_transpose2d_bf16_fwd(ctypes.byref(d), xd.data_ptr(), wp.data_ptr(), y.data_ptr(), ctypes.byref(ep), rt.stream),
             "vcg_conv_transpose2d_bf16_fwd")
     got = _to_nchw_f32(rt, y).cpu().double()
-    ref = K.conv2d_transpose_same(_bf16_round(x), _bf16_round(wk), None, 2)
+    ref = K.conv2d_transpose_same(_bf16_round(x), _bf16_round(wk), bias.double(), 2)
     if lrelu:
         ref = torch.where(ref >= 0, ref, 0.2 * ref)
     e = rel_err(got, ref)
@@ -159,7 +161,7 @@ F9_CASES = [
     # n, h, w, tanh
     (1, 20, 64, True),
     (2, 37, 70, True),            # two strips (ragged), rows not a multiple of anything
-    (1, 140, 40, False),          # two row segments
+    (1, 140, 40, False),          # several row segments
     (1, 6, 9, True),
 ]
 
@@ -186,3 +188,50 @@ def test_final_conv9x9_256to3_bf16(rt, n, h, w, tanh):
     e = rel_err(y.cpu().double(), ref)
     report("bf16 final conv9x9 256->3 n=%d %dx%d tanh=%s  err=%.2e (fp32 output)" % (n, h, w, tanh, e))
     assert e < 1e-4          # bf16 operands are exact in both; only the fp32 accumulation order differs
+
+
+def _randomize_bn(G, seed):
+    """non-trivial BatchNormalization statistics / affine parameters / PReLU slopes, as after training"""
+    rng = np.random.RandomState(seed)
+    w = G.get_weights_dict()
+    for k, v in w.items():
+        if k.endswith("/gamma"):
+            w[k] = rng.uniform(0.7, 1.3, v.shape).astype(np.float32)
+        elif k.endswith(("/beta", "/moving_mean", "/bias")):
+            w[k] = rng.uniform(-0.2, 0.2, v.shape).astype(np.float32)
+        elif k.endswith("/moving_variance"):
+            w[k] = rng.uniform(0.5, 1.5, v.shape).astype(np.float32)
+        elif k.endswith("/alpha"):
+            w[k] = rng.uniform(0.0, 0.3, v.shape).astype(np.float32)
+    G.set_weights_dict(w)
+    return w
+
+
+@pytest.mark.parametrize("res,n,h,w", [(2, 2, 24, 40), (9, 1, 32, 32)])
+def test_bf16_generator_matches_oracle_predict(rt, res, n, h, w):
+    """C5: the whole inference pass (BN folded, bf16 storage, hipGraph replay) against the fp64 oracle's predict.
+    bf16 storage rounds every activation tensor (2^-9 relative each, 2*res+3 tensors deep), so the end-to-end bound is
+    looser than the per-kernel one: 3e-2 of the output range, with the fp32 product's 1e-3 beside it."""
+    from oracle import models as M
+    from upscaler import model as PM
+    G = PM.make_upscaler_orig((2 * h, 2 * w, 3), kernel_size=3, upscale_factor=2, res_block_num=res, seed=7)
+    wd = _randomize_bn(G, 3)
+    x = (np.random.RandomState(1).randint(0, 256, (n, h, w, 3)) / 127.5 - 1).astype(np.float32)
+    ow = M.to_torch(wd, torch.float64)
+    with torch.no_grad():
+        ref, _ = M.upscaler_orig_forward(ow, torch.tensor(x, dtype=torch.float64), False, res, 2)        # NHWC in / out
+    ref = ref.numpy()
+    inf = G.to_inference_bf16()
+    got = inf.predict(x)
+    got2 = inf.predict(x)                                   # second call: pure graph replay
+    assert np.array_equal(got, got2)
+    e_bf16 = rel_err(got, ref)
+    e_fp32 = rel_err(G.predict(x), ref)
+    report("bf16 generator predict res=%d n=%d %dx%d  err=%.2e (fp32 product path %.2e)" % (res, n, h, w, e_bf16, e_fp32))
+    assert e_fp32 < 1e-3
+    assert e_bf16 < 3e-2
+    # image-level: the uint8 frames differ by at most a few grey levels
+    u_ref = np.around((ref + 1) * 127.5)
+    u_got = np.around((got.astype(np.float64) + 1) * 127.5)
+    report("bf16 generator uint8 frame difference: max %d levels, mean %.3f" % (np.abs(u_ref - u_got).max(), np.abs(u_ref - u_got).mean()))
+    assert np.abs(u_ref - u_got).max() <= 6

@@ -336,6 +336,7 @@ constexpr int TNPRE = (TNCHUNK + NLW * 64 - 1) / (NLW * 64);
 struct CTParams {
     const uint4* x;
     const uint4* w;          // packed [9][cout][64]
+    const float* shift;      // bias [cout] or null
     __bf16* y;
     int n, h, w_, cout, tiles_x, tiles_y, total;    // total = n * tiles_y * tiles_x (per output-channel block)
     float slope;             // LeakyReLU slope (1 = none)
@@ -366,6 +367,8 @@ __global__ __launch_bounds__(NT, 1) void convt3x3_c64_bf16_kernel(CTParams p) {
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, hh = lane >> 5;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nblk = p.cout >> 6, cb = blockIdx.x % nblk, wg = blockIdx.x / nblk, nwg = gridDim.x / nblk;
+    float* prm = (float*)(smem + WB + TXB);          // bias of this block's 64 channels
+    if (tid < 64) prm[tid] = p.shift ? p.shift[cb * 64 + tid] : 0.f;
 
     for (int c = tid; c < 9 * 64 * 8; c += NT) {
         const int chunk = c & 7, co = (c >> 3) & 63, tap = c >> 9;
@@ -471,7 +474,9 @@ __global__ __launch_bounds__(NT, 1) void convt3x3_c64_bf16_kernel(CTParams p) {
                     for (int q = 0; q < 2; ++q)
 #pragma unroll
                         for (int pt = 0; pt < 2; ++pt) {
-                            float v[8];
+                            float v[8], sh[8];
+                            *(f32x4*)&sh[0] = *(const f32x4*)(prm + mt * 32 + 16 * q + 8 * hh);
+                            *(f32x4*)&sh[4] = *(const f32x4*)(prm + mt * 32 + 16 * q + 8 * hh + 4);
 #pragma unroll
                             for (int j = 0; j < 4; ++j) {
                                 float lo = acc[mt][pt][8 * q + j], hi = acc[mt][pt][8 * q + 4 + j];
@@ -482,7 +487,8 @@ __global__ __launch_bounds__(NT, 1) void convt3x3_c64_bf16_kernel(CTParams p) {
                             bf16x8 ov;
 #pragma unroll
                             for (int j = 0; j < 8; ++j) {
-                                const float u = v[j] >= 0.f ? v[j] : v[j] * p.slope;
+                                const float b = v[j] + sh[j];
+                                const float u = b >= 0.f ? b : b * p.slope;
                                 ov[j] = (__bf16)u;
                             }
                             const int gy = gy0 + pt;
@@ -512,8 +518,7 @@ __global__ __launch_bounds__(NT, 1) void convt3x3_c64_bf16_kernel(CTParams p) {
 //     wave stay in 144 VGPRs; the four partial output rows meet in LDS once per row (768 B per wave);
 //   * the wave's 72-pixel x 64-channel slice of the input row goes HBM -> LDS by global_load_lds (no VGPRs), double
 //     buffered, XOR-swizzled on the global side so that the shifted ds_read_b128 of all 9 kx are conflict-free;
-//   * work item = (image, 64-column strip, segment of F_SH output rows); 2 workgroups per CU.
-constexpr int F_SH = 128;                    // output rows per work item (8 halo rows are recomputed per segment)
+//   * work item = (image, 64-column strip, segment of 32..128 output rows); 2 workgroups per CU.
 constexpr int F_PIX = 72;                    // 64 output columns + 4 + 4
 constexpr int F_ROWB = F_PIX * 128;          // one wave's slice of one input row in LDS (9216 B)
 constexpr int F_LDS = 4 * 2 * F_ROWB + 2 * 4 * 3 * 64 * 4;
@@ -524,7 +529,7 @@ struct F9Params {
     const uint4* wfrag;          // packed [4 chunks][9 kx][4 s][64 lanes] x 16 B, followed by 64 zero bytes
     const float* bias;           // [3] or null
     float* y;                    // fp32 NCHW [n][3][h][w]
-    int n, h, w_, strips, segs, total;
+    int n, h, w_, strips, segs, sh, total;      // sh: output rows per work item (8 halo rows are recomputed per item)
     int tanh_act;
 };
 
@@ -560,7 +565,7 @@ __global__ __launch_bounds__(256, 2) void conv9x9_c256to3_bf16_kernel(F9Params p
 
     for (int item = blockIdx.x; item < p.total; item += gridDim.x) {
         const int seg = item % p.segs, i2 = item / p.segs, strip = i2 % p.strips, img = i2 / p.strips;
-        const int x0 = strip * 64, y0 = seg * F_SH, y1 = min(y0 + F_SH, p.h);
+        const int x0 = strip * 64, y0 = seg * p.sh, y1 = min(y0 + p.sh, p.h);
 
         auto dma = [&](int yi, int buf) {
             const bool rowok = (unsigned)yi < (unsigned)p.h;
@@ -781,13 +786,14 @@ int vcg_conv_transpose2d_bf16_fwd(const vcg_conv_desc* d, const void* x, const v
     if (d->n <= 0 || d->h <= 0 || d->w <= 0) return VCG_E_SHAPE;
     if (d->oh != 2 * d->h || d->ow != 2 * d->w || d->stride != 2) return VCG_E_SHAPE;
     const int act = ep ? ep->act : VCG_ACT_NONE;
-    if (ep && (ep->scale || ep->shift || ep->residual)) return VCG_E_UNSUPPORTED;
+    if (ep && (ep->scale || ep->residual)) return VCG_E_UNSUPPORTED;
     if (act != VCG_ACT_NONE && act != VCG_ACT_LRELU) return VCG_E_UNSUPPORTED;
     const int nblk = d->cout / 64;
     if (d->cin != 64 || d->cout % 64 != 0 || (nblk & (nblk - 1)) != 0 || nblk > 8 || d->kh != 3 || d->kw != 3) return VCG_E_UNSUPPORTED;
     CTParams p;
     p.x = (const uint4*)x;
     p.w = (const uint4*)w_packed;
+    p.shift = ep ? (const float*)ep->shift : nullptr;
     p.y = (__bf16*)y;
     p.n = d->n;
     p.h = d->h;
@@ -799,13 +805,13 @@ int vcg_conv_transpose2d_bf16_fwd(const vcg_conv_desc* d, const void* x, const v
     p.slope = act == VCG_ACT_LRELU ? ep->act_alpha : 1.f;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)convt3x3_c64_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WB + TXB);
+        hipError_t e = hipFuncSetAttribute((const void*)convt3x3_c64_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WB + TXB + 256);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
     int per = 256 / nblk;                       // workgroups per output-channel block
     if (per > p.total) per = p.total;
-    convt3x3_c64_bf16_kernel<<<per * nblk, NT, WB + TXB, stream>>>(p);
+    convt3x3_c64_bf16_kernel<<<per * nblk, NT, WB + TXB + 256, stream>>>(p);
     VCG_LAUNCH_CHECK();
     return VCG_OK;
 }
@@ -835,7 +841,9 @@ int vcg_conv9x9_to3_bf16_fwd(const vcg_conv_desc* d, const void* x, const void* 
     p.h = d->h;
     p.w_ = d->w;
     p.strips = ceil_div(d->w, 64);
-    p.segs = ceil_div(d->h, F_SH);
+    p.sh = 128;                                   // shorter segments (more halo recompute) until the chip is filled twice
+    while (p.sh > 32 && p.n * p.strips * ceil_div(d->h, p.sh) < 1024) p.sh >>= 1;
+    p.segs = ceil_div(d->h, p.sh);
     p.total = p.n * p.strips * p.segs;
     p.tanh_act = tanh_act;
     static bool attr_set = false;

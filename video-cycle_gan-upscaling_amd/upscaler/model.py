@@ -309,6 +309,11 @@ class UpscalerOrig(Model):
     def _out_shape(self, s):
         return (s[0] * self.factor, s[1] * self.factor, 3)
 
+    def to_inference_bf16(self):
+        """inference engine on the bf16-storage kernels (BN folded, one hipGraph per input shape): ``_infer.py``"""
+        from ._infer import Bf16Generator
+        return Bf16Generator(self)
+
     def forward(self, x, training):
         tape = []
         h, c = self.c_init.forward(x); tape.append(c)
