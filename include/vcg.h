@@ -151,6 +151,12 @@ int vcg_fill(float* y, size_t count, float value, vcg_stream_t stream);
 /* y = a*x + b*y */
 int vcg_axpby(const float* x, float* y, size_t count, float a, float b, vcg_stream_t stream);
 
+/* MaxPooling2D((2,2), strides (2,2), 'valid') of the VGG19 feature extractor behind VGG_LOSS / VGG_MSE_LOSS /
+ * VGG_MAE_LOSS (upscaling/upscaler/model.py:101-157; keras.applications.VGG19 block{1..4}_pool).  fp32 NCHW;
+ * y: [n,c,h/2,w/2] (floor).  bwd: gradient to the first maximal element of each window (row-major), x = forward input. */
+int vcg_maxpool2x2_fwd(const float* x, float* y, int n, int c, int h, int w, vcg_stream_t stream);
+int vcg_maxpool2x2_bwd(const float* x, const float* dy, float* dx, int n, int c, int h, int w, vcg_stream_t stream);
+
 /* ---- Adam(): keras.optimizers.Adam defaults, model.py:1026,1066,1130 -------------------------- */
 /* multi-tensor update over one flat parameter buffer; lr_t = lr*sqrt(1-b2^t)/(1-b1^t) is computed
  * by the caller; p -= lr_t * m / (sqrt(v) + eps) */

@@ -249,3 +249,37 @@ def discriminator_patchgan_70_forward(w, x_nhwc, training, activation="none", no
 
 def count_params(w):
     return int(sum(int(np.prod(v.shape)) for v in w.values()))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# keras.applications.VGG19(include_top=False) up to block5_conv4: the feature extractor of VGG_LOSS / VGG_MSE_LOSS /
+# VGG_MAE_LOSS (reference: upscaling/upscaler/model.py:101-157).  The reference feeds it the [-1,1] frames as they
+# are (no ImageNet preprocessing) and takes the ReLU'd output of block5_conv4.  The ImageNet weights cannot be
+# fetched offline; parity runs use seeded random weights of the same shapes (He-uniform, so that activations keep
+# their scale through 16 ReLU layers).
+# ---------------------------------------------------------------------------------------------------------------
+VGG19_BLOCKS = ((1, 2, 64), (2, 2, 128), (3, 4, 256), (4, 4, 512), (5, 4, 512))
+
+
+def init_vgg19_features(seed=19, cin=3):
+    rng = np.random.RandomState(seed)
+    w = OrderedDict()
+    for b, nconv, f in VGG19_BLOCKS:
+        for i in range(nconv):
+            lim = np.sqrt(6.0 / (9 * cin))
+            w["block%d_conv%d/kernel" % (b, i + 1)] = rng.uniform(-lim, lim, (3, 3, cin, f)).astype(np.float32)
+            w["block%d_conv%d/bias" % (b, i + 1)] = rng.uniform(-0.05, 0.05, (f,)).astype(np.float32)
+            cin = f
+    return w
+
+
+def vgg19_block5_conv4(w, x_nhwc):
+    """VGG19 features: 3x3 'same' conv + ReLU stacks with 2x2/2 'valid' max pooling after blocks 1-4."""
+    x = x_nhwc.permute(0, 3, 1, 2)
+    for b, nconv, _ in VGG19_BLOCKS:
+        for i in range(nconv):
+            n = "block%d_conv%d" % (b, i + 1)
+            x = torch.relu(K.conv2d(x, w[n + "/kernel"], w[n + "/bias"], 1, "same"))
+        if b < 5:
+            x = torch.nn.functional.max_pool2d(x, 2, 2)
+    return x.permute(0, 2, 3, 1)

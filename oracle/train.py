@@ -38,11 +38,21 @@ class _Slots:
         self.v = OrderedDict((k, torch.full_like(v, v0)) for k, v in weights.items() if is_trainable(k))
 
 
-def content_loss_value(kind, y_true, y_pred):
+def content_loss_value(kind, y_true, y_pred, vgg_w=None):
+    """'mse' / 'mae' pixel losses, or the VGG19 perceptual losses of the reference (model.py:101-157):
+    ('vgg',) = VGG_LOSS, ('vgg_mse', rate) = VGG_MSE_LOSS, ('vgg_mae', rate) = VGG_MAE_LOSS; vgg_w = VGG19 weights."""
     if kind in ("mse", "mean_squared_error"):
         return ((y_pred - y_true) ** 2).mean()
     if kind in ("mae", "mean_absolute_error"):
         return (y_pred - y_true).abs().mean()
+    if isinstance(kind, tuple) and kind[0] in ("vgg", "vgg_mse", "vgg_mae"):
+        from . import models as M
+        ft, fp = M.vgg19_block5_conv4(vgg_w, y_true), M.vgg19_block5_conv4(vgg_w, y_pred)
+        if kind[0] == "vgg":
+            return ((ft - fp) ** 2).mean()                                                      # model.py:116
+        if kind[0] == "vgg_mse":
+            return ((ft - fp) ** 2).mean() + kind[1] * ((y_true - y_pred) ** 2).mean()          # model.py:137
+        return (ft - fp).abs().mean() + kind[1] * (y_true - y_pred).abs().mean()                # model.py:157
     raise ValueError(kind)
 
 
@@ -53,13 +63,14 @@ class GanOracle:
 
     def __init__(self, g_forward, g_w, d_forward, d_w, wiring="gan2", content="mse",
                  content_loss_weight=1.0, losses="wass", loss_activation="log-sigm",
-                 discriminator_loss_weight=1e-5, optimizer=None, adam_v0=0.0):
+                 discriminator_loss_weight=1e-5, optimizer=None, adam_v0=0.0, vgg_w=None):
         """adam_v0: initial value of Adam's second-moment slots.  Keras starts at 0, which makes the first
         updates sign-like (|step| = lr whatever the gradient) and any fp32-vs-fp64 comparison after one step
         chaotic; parity runs that look past the first update prime the slots instead (tests only)."""
         self.g_forward, self.d_forward = g_forward, d_forward
         self.g_w, self.d_w = g_w, d_w
         self.wiring, self.content = wiring, content
+        self.vgg_w = vgg_w
         self.cw, self.dw = content_loss_weight, discriminator_loss_weight
         self.losses, self.loss_activation = losses, loss_activation
         self.opt = optimizer or SharedAdam()
@@ -142,7 +153,7 @@ class GanOracle:
         fake, g_upd = self.g_forward(g_leaf, lr, True)
         self.last_fake_train = fake.detach()
         d_fake, _ = self.d_forward(d_frozen, fake, True)
-        content = content_loss_value(self.content, hr, fake)
+        content = content_loss_value(self.content, hr, fake, self.vgg_w)
         if self.wiring == "gan2":
             if self.losses == "wass":
                 adv = d_fake.mean()                                   # model.py:230-233

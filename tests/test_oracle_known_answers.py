@@ -110,3 +110,15 @@ def test_value_map_data_py():
     assert a.min() == -1.0 and a.max() == 1.0
     assert np.array_equal(a[0, :, :, 0].reshape(-1), np.arange(256) / 127.5 - 1)
     assert np.array_equal(OD.convert_array_to_uint8(a), u8)
+
+
+def test_vgg19_notop_param_count_and_shapes():
+    """keras.applications.VGG19(include_top=False): 20,024,384 parameters; block5_conv4 is 1/16 resolution x 512
+    (the feature extractor of VGG_LOSS, upscaling/upscaler/model.py:108-112)."""
+    import torch
+    from oracle import models as M
+    w = M.init_vgg19_features()
+    assert sum(int(np.prod(v.shape)) for v in w.values()) == 20024384
+    assert len(w) == 32 and w["block1_conv1/kernel"].shape == (3, 3, 3, 64) and w["block5_conv4/kernel"].shape == (3, 3, 512, 512)
+    f = M.vgg19_block5_conv4(M.to_torch(w), torch.zeros(1, 32, 48, 3))
+    assert tuple(f.shape) == (1, 2, 3, 512) and float(f.min()) >= 0.0

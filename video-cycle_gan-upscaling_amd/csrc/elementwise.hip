@@ -17,7 +17,7 @@ inline int pick_split_cs(int c, size_t per_channel) {
 __device__ __forceinline__ float act_bwd_one(float s, float d, int act, float al, float& dal) {
     float g;
     if (act == VCG_ACT_TANH) g = 1.f - s * s;                 // saved = output
-    else if (act == VCG_ACT_LRELU) g = s >= 0.f ? 1.f : al;   // saved = output (slope > 0 keeps the sign)
+    else if (act == VCG_ACT_LRELU) g = s > 0.f ? 1.f : al;    // saved = output; '>' as TF's LeakyReluGrad: exact for slope 0 (ReLU) too
     else if (act == VCG_ACT_PRELU) { g = s > 0.f ? 1.f : al; dal += d * fminf(s, 0.f); }  // saved = input
     else g = 1.f;
     return d * g;
@@ -229,6 +229,43 @@ __global__ void nchw_to_nhwc_kernel(const float* src, float* dst, int n, int h, 
     dst[i] = src[((nn * c + ch) * h + y) * w + x];
 }
 
+// MaxPooling2D((2,2), strides (2,2), 'valid') of keras.applications.VGG19 (the perceptual losses, model.py:101-157)
+__global__ void maxpool2x2_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, size_t planes, int h, int w) {
+    const int oh = h >> 1, ow = w >> 1;
+    const size_t total = planes * oh * ow;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int ox = (int)(i % ow), oy = (int)((i / ow) % oh);
+    const size_t pl = i / ((size_t)ow * oh);
+    const float* s = x + (pl * h + 2 * oy) * w + 2 * ox;
+    y[i] = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[w], s[w + 1]));
+}
+
+// gradient to the FIRST maximal element of each window in row-major order (TF / torch convention); rows / columns
+// beyond 2*floor(h/2) take no part in any window and get zero
+__global__ void maxpool2x2_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx,
+                                      size_t planes, int h, int w) {
+    const int oh = h >> 1, ow = w >> 1;
+    const size_t total = planes * h * w;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int ix = (int)(i % w), iy = (int)((i / w) % h);
+    const size_t pl = i / ((size_t)w * h);
+    const int oy = iy >> 1, ox = ix >> 1;
+    float g = 0.f;
+    if (oy < oh && ox < ow) {
+        const float* s = x + (pl * h + 2 * oy) * w + 2 * ox;
+        const float v0 = s[0], v1 = s[1], v2 = s[w], v3 = s[w + 1];
+        int arg = 0;
+        float m = v0;
+        if (v1 > m) { m = v1; arg = 1; }
+        if (v2 > m) { m = v2; arg = 2; }
+        if (v3 > m) { m = v3; arg = 3; }
+        if (arg == (iy & 1) * 2 + (ix & 1)) g = dy[(pl * oh + oy) * ow + ox];
+    }
+    dx[i] = g;
+}
+
 // (taps, a, b) -> (taps, b, a), LDS-tiled 32x32 transpose
 __global__ __launch_bounds__(256) void kernel_transpose_kernel(const float* src, float* dst, int a, int b) {
     __shared__ float tile[32][33];
@@ -421,6 +458,24 @@ int vcg_kernel_transpose(const float* src, float* dst, int taps, int a, int b, v
     if (taps <= 0 || a <= 0 || b <= 0 || taps > 65535) return VCG_E_SHAPE;
     hipLaunchKernelGGL(kernel_transpose_kernel, dim3(ceil_div(b, 32), ceil_div(a, 32), taps), dim3(256), 0,
                        (hipStream_t)stream, src, dst, a, b);
+    VCG_LAUNCH_CHECK();
+    return VCG_OK;
+}
+
+int vcg_maxpool2x2_fwd(const float* x, float* y, int n, int c, int h, int w, vcg_stream_t stream) {
+    VCG_CHECK_PTR(x); VCG_CHECK_PTR(y);
+    if (n <= 0 || c <= 0 || h < 2 || w < 2) return VCG_E_SHAPE;
+    const size_t total = (size_t)n * c * (h >> 1) * (w >> 1);
+    hipLaunchKernelGGL(maxpool2x2_fwd_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, x, y, (size_t)n * c, h, w);
+    VCG_LAUNCH_CHECK();
+    return VCG_OK;
+}
+
+int vcg_maxpool2x2_bwd(const float* x, const float* dy, float* dx, int n, int c, int h, int w, vcg_stream_t stream) {
+    VCG_CHECK_PTR(x); VCG_CHECK_PTR(dy); VCG_CHECK_PTR(dx);
+    if (n <= 0 || c <= 0 || h < 2 || w < 2) return VCG_E_SHAPE;
+    const size_t total = (size_t)n * c * h * w;
+    hipLaunchKernelGGL(maxpool2x2_bwd_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, x, dy, dx, (size_t)n * c, h, w);
     VCG_LAUNCH_CHECK();
     return VCG_OK;
 }

@@ -157,7 +157,7 @@ __global__ __launch_bounds__(256) void norm_act_fwd_flat_kernel(const float* x, 
 
 // ---- backward -------------------------------------------------------------------------------------
 __device__ __forceinline__ float act_grad(float z, int act, float al) {
-    if (act == VCG_ACT_LRELU) return z >= 0.f ? 1.f : al;
+    if (act == VCG_ACT_LRELU) return z > 0.f ? 1.f : al;
     if (act == VCG_ACT_PRELU) return z > 0.f ? 1.f : al;
     return 1.f;
 }

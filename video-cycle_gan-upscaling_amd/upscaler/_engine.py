@@ -524,6 +524,21 @@ def to_nhwc(rt, t):
     return out
 
 
+def maxpool2x2(rt, x):
+    """MaxPooling2D((2,2)) forward: fp32 NCHW -> [n,c,h//2,w//2]"""
+    n, c, h, w = x.shape
+    y = rt.empty(n, c, h // 2, w // 2)
+    L.check(rt.lib.vcg_maxpool2x2_fwd(x.data_ptr(), y.data_ptr(), n, c, h, w, rt.stream), "vcg_maxpool2x2_fwd")
+    return y
+
+
+def maxpool2x2_bwd(rt, x, dy):
+    n, c, h, w = x.shape
+    dx = rt.empty(n, c, h, w)
+    L.check(rt.lib.vcg_maxpool2x2_bwd(x.data_ptr(), dy.data_ptr(), dx.data_ptr(), n, c, h, w, rt.stream), "vcg_maxpool2x2_bwd")
+    return dx
+
+
 def mean_scalar(rt, t):
     """device scalar tensor holding mean(t) (vcg_mean_reduce)."""
     out = rt.empty(1)

@@ -58,8 +58,7 @@ def mean_absolute_error(y_true, y_pred):
 
 
 class PixelLoss:
-    """Pixel content loss = the non-VGG term of VGG_MSE_LOSS / VGG_MAE_LOSS (model.py:137,157); the VGG19
-    perceptual term needs downloaded ImageNet weights and is out of scope."""
+    """Pixel content loss = the non-VGG term of VGG_MSE_LOSS / VGG_MAE_LOSS (model.py:137,157)."""
 
     def __init__(self, kind="mse"):
         if kind not in ("mse", "mae"):
@@ -70,7 +69,64 @@ class PixelLoss:
         return mean_squared_error(y_true, y_pred) if self.kind == "mse" else mean_absolute_error(y_true, y_pred)
 
 
+VGG19_BLOCKS = ((1, 2, 64), (2, 2, 128), (3, 4, 256), (4, 4, 512), (5, 4, 512))
+
+
+class _VggLossBase:
+    """Shared constructor of VGG_LOSS / VGG_MSE_LOSS / VGG_MAE_LOSS (model.py:101-157).
+
+    The reference builds ``VGG19(include_top=False, weights='imagenet')`` -- a download this offline image cannot
+    make.  ``vgg19`` therefore names the weights instead of being a Keras model: a ``VGG19Features`` instance, a
+    path to a .safetensors / .npz archive or a dict with Keras' layer names (``block1_conv1/kernel`` (3,3,3,64) ...
+    ``block5_conv4/bias``), or the string ``'random'`` (seeded He-uniform: throughput runs and parity tests).
+    ``vgg19=None`` raises, because silently training against random features is not what the caller asked for."""
+    kind, rate = "vgg", 0.0
+
+    def __init__(self, image_shape, vgg19=None):
+        self.image_shape = tuple(image_shape)
+        if vgg19 is None:
+            raise RuntimeError("VGG19 ImageNet weights cannot be downloaded here: pass vgg19=<path to a .safetensors/.npz with "
+                               "Keras' VGG19 layer names> (or a dict of arrays), or vgg19='random' for synthetic runs")
+        self.model = vgg19 if isinstance(vgg19, VGG19Features) else VGG19Features(self.image_shape, vgg19)
+        self.model.trainable = False
+
+    def loss(self, y_true, y_pred):
+        """host evaluation on NHWC arrays (the training models evaluate it on the device)"""
+        ft, fp = self.model.predict(np.asarray(y_true)), self.model.predict(np.asarray(y_pred))
+        d, dp = ft - fp, np.asarray(y_true) - np.asarray(y_pred)
+        if self.kind == "vgg_mae":
+            return float(np.mean(np.abs(d)) + self.rate * np.mean(np.abs(dp)))
+        return float(np.mean(d * d) + self.rate * np.mean(dp * dp))
+
+
+class VGG_LOSS(_VggLossBase):
+    """mean((VGG(y_true) - VGG(y_pred))^2) at block5_conv4 (model.py:101-116)"""
+
+
+class VGG_MSE_LOSS(_VggLossBase):
+    """VGG_LOSS + mse_loss_rate * pixel MSE (model.py:119-137)"""
+    kind = "vgg_mse"
+
+    def __init__(self, image_shape, mse_loss_rate=0.1, vgg19=None):
+        super().__init__(image_shape, vgg19)
+        self.mse_loss_rate = self.rate = float(mse_loss_rate)
+
+
+class VGG_MAE_LOSS(_VggLossBase):
+    """mean|VGG(y_true) - VGG(y_pred)| + mae_loss_rate * pixel MAE (model.py:139-157)"""
+    kind = "vgg_mae"
+
+    def __init__(self, image_shape, mae_loss_rate=0.1, vgg19=None):
+        super().__init__(image_shape, vgg19)
+        self.mae_loss_rate = self.rate = float(mae_loss_rate)
+
+
 def _content_kind(content_loss):
+    owner = getattr(content_loss, "__self__", None)
+    if isinstance(owner, _VggLossBase):
+        return owner
+    if isinstance(content_loss, _VggLossBase):
+        return content_loss
     if isinstance(content_loss, str):
         k = {"mse": "mse", "mean_squared_error": "mse", "mae": "mae", "mean_absolute_error": "mae"}.get(content_loss)
         if k is None:
@@ -86,8 +142,8 @@ def _content_kind(content_loss):
     if isinstance(content_loss, PixelLoss):
         return content_loss.kind
     raise NotImplementedError(
-        "content loss %r is not on the MI355X hot path: use 'mse'/'mae' or PixelLoss(kind).loss "
-        "(the VGG19 perceptual losses need ImageNet weights, SURVEY.md section 8f)" % (content_loss,))
+        "content loss %r is not on the MI355X hot path: use 'mse'/'mae', PixelLoss(kind).loss or "
+        "VGG_LOSS / VGG_MSE_LOSS / VGG_MAE_LOSS(image_shape, ..., vgg19=<weights>).loss" % (content_loss,))
 
 
 def _act_value_and_grad(name, x):
@@ -273,6 +329,69 @@ class Model:
 
     def __call__(self, x):
         return self.predict(x)
+
+
+class VGG19Features(Model):
+    """keras.applications.VGG19(include_top=False) up to block5_conv4 -- the frozen feature extractor of the perceptual
+    losses (model.py:108-112).  3x3 'same' convolutions with fused ReLU, 2x2 max pooling after blocks 1-4; only the
+    data gradient is ever needed (``backward_data``)."""
+
+    def __init__(self, image_shape, weights="random", seed=19):
+        super().__init__("vgg19_block5_conv4", image_shape, seed)
+        self.trainable = False
+        self.stages = []
+        cin = image_shape[2]
+        for b, nconv, f in VGG19_BLOCKS:
+            convs = []
+            for i in range(nconv):
+                convs.append(self._add(E.Conv2D("block%d_conv%d" % (b, i + 1), cin, f, 3, act=L.ACT_LRELU, alpha=0.0)))
+                cin = f
+            self.stages.append((convs, b < 5))
+        self._finish()
+        if isinstance(weights, str) and weights == "random":
+            rng = np.random.RandomState(seed)            # He-uniform (oracle/models.py:init_vgg19_features draws the same)
+            w, cin = {}, image_shape[2]
+            for b, nconv, f in VGG19_BLOCKS:
+                for i in range(nconv):
+                    lim = np.sqrt(6.0 / (9 * cin))
+                    w["block%d_conv%d/kernel" % (b, i + 1)] = rng.uniform(-lim, lim, (3, 3, cin, f)).astype(np.float32)
+                    w["block%d_conv%d/bias" % (b, i + 1)] = rng.uniform(-0.05, 0.05, (f,)).astype(np.float32)
+                    cin = f
+            self.set_weights_dict(w)
+        elif isinstance(weights, dict):
+            self.set_weights_dict({k: np.asarray(v, np.float32) for k, v in weights.items()})
+        else:
+            path = str(weights)
+            if path.endswith(".npz"):
+                self.set_weights_dict({k: v.astype(np.float32) for k, v in np.load(path).items()})
+            else:
+                self.load_weights(path)
+
+    def _out_shape(self, s):
+        return (s[0] // 16, s[1] // 16, 512)
+
+    def forward(self, x, training=False):
+        tape = []
+        h = x
+        for convs, pool in self.stages:
+            for c in convs:
+                h, a = c.forward(h, tag="vgg_conv")
+                tape.append(a)
+            if pool:
+                tape.append(h)
+                h = E.maxpool2x2(self.rt, h)
+        return h, tape
+
+    def backward_data(self, tape, dy):
+        """dL/d(input image) from dL/d(features); no parameter gradients (the network is frozen)"""
+        tape = list(tape)
+        d = dy
+        for convs, pool in reversed(self.stages):
+            if pool:
+                d = E.maxpool2x2_bwd(self.rt, tape.pop(), d)
+            for c in reversed(convs):
+                d = c.backward(tape.pop(), d, True, False, 0, tag="vgg_conv")
+        return d
 
 
 class UpscalerOrig(Model):
@@ -507,6 +626,34 @@ def make_discriminator_patchgan_70(input_shape, activation="none", norm="instanc
 # =================================================================================================
 # training wiring -- make_and_compile_gan / make_and_compile_gan2 / compile_training_model
 # =================================================================================================
+def _pixel_loss(rt, pred, target, kind, scale):
+    """(value [1], d(scale * value)/d pred) of the mean squared / absolute difference of two device tensors"""
+    val, dpred = rt.empty(1), rt.empty(*pred.shape)
+    ws, wsn = rt.workspace(rt.lib.vcg_mean_reduce_workspace_bytes(pred.numel()))
+    L.check(rt.lib.vcg_pixel_loss(pred.data_ptr(), target.data_ptr(), pred.numel(), L.LOSS_MSE if kind == "mse" else L.LOSS_MAE,
+                                  float(scale), val.data_ptr(), dpred.data_ptr(), ws, wsn, rt.stream), "vcg_pixel_loss")
+    return val, dpred
+
+
+def _content_loss_and_grad(rt, kind, weight, fake, hr):
+    """content loss value (device scalar, unweighted) and d(weight * loss)/d fake for 'mse' / 'mae' or a VGG19
+    perceptual loss object (model.py:101-157): features of hr and fake at block5_conv4, their mean squared / absolute
+    difference, its gradient back through the frozen VGG19 to the fake frames, plus ``rate`` x the pixel term."""
+    if isinstance(kind, str):
+        return _pixel_loss(rt, fake, hr, kind, weight)
+    vgg = kind.model
+    f_real, _ = vgg.forward(hr)
+    f_fake, tape = vgg.forward(fake)
+    pk = "mae" if kind.kind == "vgg_mae" else "mse"
+    val, dfeat = _pixel_loss(rt, f_fake, f_real, pk, weight)
+    dfake = vgg.backward_data(tape, dfeat)
+    if kind.rate:
+        pval, dpix = _pixel_loss(rt, fake, hr, pk, weight * kind.rate)
+        E.axpby(rt, dpix, dfake, 1.0, 1.0)
+        E.axpby(rt, pval, val, kind.rate, 1.0)
+    return val, dfake
+
+
 class _Slots:
     """Adam m/v for one compiled model (Keras creates separate slots per get_updates call)."""
 
@@ -630,12 +777,7 @@ class GanTrainer:
         rt, G, D = self.rt, self.G, self.D
         fake, gtape = G.forward(lr, True)
         out_f, dtape = D.forward(fake, True, False)          # frozen D: batch stats, no moving update
-        content = rt.empty(1)
-        dfake = rt.empty(*fake.shape)
-        ws, wsn = rt.workspace(rt.lib.vcg_mean_reduce_workspace_bytes(fake.numel()))
-        L.check(rt.lib.vcg_pixel_loss(fake.data_ptr(), hr.data_ptr(), fake.numel(),
-                                      L.LOSS_MSE if self.content_kind == "mse" else L.LOSS_MAE, self.cw, content.data_ptr(),
-                                      dfake.data_ptr(), ws, wsn, rt.stream), "vcg_pixel_loss")
+        content, dfake = _content_loss_and_grad(rt, self.content_kind, self.cw, fake, hr)
         mf = self._mean(out_f)
         adv = mf
         g = 1.0
@@ -843,8 +985,8 @@ class _GeneratorOnlyTrainer:
 
 
 class GeneratorTrainingModel:
-    """compile_training_model(upscaler, loss) (model.py:1130-1137): generator-only training with the
-    pixel loss."""
+    """compile_training_model(upscaler, loss) (model.py:1130-1137): generator-only training with a pixel or
+    VGG19 perceptual loss."""
 
     def __init__(self, upscaler, loss, optimizer):
         self.G, self.kind, self.opt = upscaler, _content_kind(loss), optimizer
@@ -859,11 +1001,7 @@ class GeneratorTrainingModel:
         rt, G = self.rt, self.G
         lr, hr = E.to_device_nchw(rt, x), E.to_device_nchw(rt, y)
         fake, tape = G.forward(lr, True)
-        val, dfake = rt.empty(1), rt.empty(*fake.shape)
-        ws, wsn = rt.workspace(rt.lib.vcg_mean_reduce_workspace_bytes(fake.numel()))
-        L.check(rt.lib.vcg_pixel_loss(fake.data_ptr(), hr.data_ptr(), fake.numel(),
-                                      L.LOSS_MSE if self.kind == "mse" else L.LOSS_MAE, 1.0, val.data_ptr(), dfake.data_ptr(),
-                                      ws, wsn, rt.stream), "vcg_pixel_loss")
+        val, dfake = _content_loss_and_grad(rt, self.kind, 1.0, fake, hr)
         G.backward(tape, dfake, 0)
         ps = G.ps
         L.check(rt.lib.vcg_adam_keras_multi(ps.params.data_ptr(), ps.grads.data_ptr(), self.slots.m.data_ptr(),
