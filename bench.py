@@ -97,6 +97,9 @@ def main():
     ap.add_argument("--lr-size", type=int, default=256, help="low-res frame edge (output is 2x)")
     ap.add_argument("--res-blocks", type=int, default=9)
     ap.add_argument("--disc", default="patchgan", choices=["patchgan", "simple"])
+    ap.add_argument("--content", default="mse", choices=["mse", "vgg_mse"],
+                    help="content loss: pixel MSE (C2 as SURVEY 8d defines it) or the reference's default VGG_MSE_LOSS form with "
+                         "seeded random VGG19 weights (ImageNet weights cannot be fetched offline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying one hipGraph per step")
     ap.add_argument("--cpu-sample-batch", type=int, default=2)
@@ -127,8 +130,9 @@ def main():
             _dist.broadcast_(m.ps.params, group)
             _dist.broadcast_(m.ps.state, group)
             m.refresh()
+    content = "mse" if args.content == "mse" else PM.VGG_MSE_LOSS((2 * h, 2 * h, 3), 0.1, vgg19="random").loss
     gen_train, disc_train, gan_train = PM.make_and_compile_gan2(
-        G, D, (h, h, 3), (2 * h, 2 * h, 3), "mse", 1.0, lambda: PM.WassersteinLosses(), 1e-5, optimizer=PM.Adam(),
+        G, D, (h, h, 3), (2 * h, 2 * h, 3), content, 1.0, lambda: PM.WassersteinLosses(), 1e-5, optimizer=PM.Adam(),
         process_group=group)
     trainer = gan_train.trainer
     rt = E.Runtime.get()
@@ -211,15 +215,15 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "C2: make_upscaler_orig((%d,%d,3),k=3,x2,res=%d) + %s, batch %d/GPU, "
-                                   "gan2 wiring, Wasserstein + pixel-MSE, faithful 3-call step incl. predict pass"
+                                   "gan2 wiring, Wasserstein + %s, faithful 3-call step incl. predict pass"
                                    % (2 * h, 2 * h, args.res_blocks, "PatchGAN-70" if args.disc == "patchgan" else "simple_512",
-                                      args.batch),
+                                      args.batch, "pixel-MSE" if args.content == "mse" else "VGG_MSE_LOSS(0.1), random VGG19 weights"),
                        "global_batch": args.batch * world, "frame": "%dx%d->%dx%d" % (h, h, 2 * h, 2 * h),
                        "parallelism": "dp%d" % world, "launch": ("hipGraph replay" if world == 1 else "3 hipGraphs per step around the 2 RCCL all-reduces") if use_graph else "eager"},
             "last_losses": [round(float(v), 6) for v in losses],
             "roofline": roof,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.content == "mse":
             out["cpu_baseline"] = cpu_baseline(args.res_blocks, args.cpu_sample_batch, h)
         print(json.dumps(out), flush=True)
     if group is not None:
