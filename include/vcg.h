@@ -163,8 +163,9 @@ int vcg_maxpool2x2_bwd(const float* x, const float* dy, float* dx, int n, int c,
 int vcg_adam_keras_multi(float* p, const float* g, float* m, float* v, size_t count, float lr_t,
                          float beta_1, float beta_2, float eps, vcg_stream_t stream);
 
-/* same update with the iteration count kept on the device: uses t = *t_dev + 1 for the bias correction and
- * then increments *t_dev, so a hipGraph that captured the call replays correctly step after step */
+/* same update with the iteration count kept on the device, so a hipGraph that captured the call replays correctly
+ * step after step.  t_dev points to TWO 32-bit words: [0] the int32 iteration count (uses t = t_dev[0] + 1 for the
+ * bias correction, then increments it), [1] scratch for lr_t (evaluated once per call, in double, by one thread) */
 int vcg_adam_keras_multi_dev(float* p, const float* g, float* m, float* v, size_t count, float lr,
                              float beta_1, float beta_2, float eps, int* t_dev, vcg_stream_t stream);
 

@@ -55,3 +55,14 @@ def test_two_rank_step_equals_whole_batch_step(tmp_path, mode):
     le = float(np.max(np.abs(two["losses"] - one["losses"]) / (np.abs(one["losses"]) + 1e-3)))
     report("dp2 (%s) vs whole batch: worst weight err=%.2e  loss err=%.2e" % (mode, worst, le))
     assert le < 1e-3
+
+
+@pytest.mark.gpu
+def test_rccl_one_rank_group_is_bit_identical():
+    """scripts/dp_nccl_smoke.py: the DP code path over a real (1-rank) RCCL communicator -- eager and as the three
+    hipGraphs around the all-reduces -- reproduces the single-process step bit for bit"""
+    script = os.path.join(os.path.dirname(HERE), "scripts", "dp_nccl_smoke.py")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, script], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert r.stdout.strip().endswith("ok")

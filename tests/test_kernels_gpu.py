@@ -243,16 +243,18 @@ def test_adam_losses_layout(rt):
     pr, mr, vr = K.adam_keras_step(p, gr, m, v, 3)
     pd, gd, md, vd = (t.float().to(rt.device) for t in (p, gr, m, v))
     import math
-    lr_t = 1e-3 * math.sqrt(1 - 0.999 ** 3) / (1 - 0.9 ** 3)
+    f32 = lambda v: float(np.float32(v))
+    lr_t = f32(1e-3) * math.sqrt(1 - f32(0.999) ** 3) / (1 - f32(0.9) ** 3)          # upscaler.model.Adam.lr_t
     L.check(lib.vcg_adam_keras_multi(pd.data_ptr(), gd.data_ptr(), md.data_ptr(), vd.data_ptr(), n, lr_t, 0.9, 0.999, 1e-7, rt.stream), "adam")
     assert max(rel_err(pd, pr), rel_err(md, mr), rel_err(vd, vr)) < 1e-5
     # graph-replayable variant: step count on the device (t = *t_dev + 1), counter incremented by the call
     pd2, gd2, md2, vd2 = (t.float().to(rt.device) for t in (p, gr, m, v))
-    t_dev = torch.tensor([2], dtype=torch.int32, device=rt.device)
+    t_dev = torch.tensor([2, 0], dtype=torch.int32, device=rt.device)          # {iteration count, lr_t scratch}
     L.check(lib.vcg_adam_keras_multi_dev(pd2.data_ptr(), gd2.data_ptr(), md2.data_ptr(), vd2.data_ptr(), n, 1e-3, 0.9, 0.999, 1e-7,
                                          t_dev.data_ptr(), rt.stream), "adam_dev")
-    assert int(t_dev.item()) == 3
+    assert int(t_dev[0].item()) == 3
     assert max(rel_err(pd2, pr), rel_err(md2, mr), rel_err(vd2, vr)) < 1e-5
+    assert torch.equal(pd2, pd) and torch.equal(md2, md) and torch.equal(vd2, vd)      # lr_t on the device == the host's double
     # pixel loss
     a, b = torch.randn(2, 3, 17, 19, generator=g, dtype=torch.float64), torch.randn(2, 3, 17, 19, generator=g, dtype=torch.float64)
     for kind, code in (("mse", L.LOSS_MSE), ("mae", L.LOSS_MAE)):
@@ -281,3 +283,16 @@ def test_adam_losses_layout(rt):
     assert torch.equal(E.to_nhwc(rt, E.to_device_nchw(rt, xs)).cpu(), xs)
     m = E.mean_scalar(rt, dev)
     assert abs(m.item() - ref.double().mean().item()) < 1e-6
+
+
+def test_assemble_training_batch_matches_loop_body(rt):
+    """train_gan3.py:341-345 on the device: same arrays as pd.concat + convert_image_series_to_array"""
+    from upscaler import data as PD
+    rng = np.random.RandomState(2)
+    hd = rng.randint(0, 256, (3, 16, 24, 3)).astype(np.uint8)
+    g1, g2, sc = (rng.randint(0, 256, (3, 8, 12, 3)).astype(np.uint8) for _ in range(3))
+    lr, hr = PD.assemble_training_batch(hd, [f for f in g1], g2, torch.from_numpy(sc))
+    ref_hr = PD.convert_image_series_to_array(list(hd) * 3)
+    ref_lr = PD.convert_image_series_to_array(list(g1) + list(g2) + list(sc))
+    assert np.array_equal(lr.permute(0, 2, 3, 1).cpu().numpy(), ref_lr.astype(np.float32))
+    assert np.array_equal(hr.permute(0, 2, 3, 1).cpu().numpy(), ref_hr.astype(np.float32))

@@ -334,7 +334,7 @@ def test_graph_replay_matches_eager(rt):
                 out.append(tr.train_step_graph(a, b))
         else:
             # same Adam kernel as the graph path (step count on the device, lr_t evaluated in fp32 there)
-            tr._t_dev = torch.tensor([opt.iterations], dtype=torch.int32, device=rt.device)
+            tr._t_dev = torch.tensor([opt.iterations, 0], dtype=torch.int32, device=rt.device)
             tr.train_step(*dev[0])
             for a, b in dev[1:]:
                 out.append(tr.train_step(a, b))

@@ -162,14 +162,23 @@ __global__ __launch_bounds__(256) void adam_kernel(float* p, const float* g, flo
     p[i] = p[i] - lr_t * mi / (sqrtf(vi) + eps);
 }
 
-// same update with the step count t read from device memory: lr_t = lr*sqrt(1-b2^t)/(1-b1^t) is evaluated on
-// the device so that a captured hipGraph replays correctly as t advances
-__global__ __launch_bounds__(256) void adam_dev_kernel(float* p, const float* g, float* m, float* v, size_t count, float lr,
-                                                       float b1, float b2, float eps, const int* t_dev) {
+// same update with the step count t kept in device memory, so that a captured hipGraph replays correctly as t
+// advances: one thread evaluates lr_t = lr*sqrt(1-b2^t)/(1-b1^t) in double (1-b2^t cancels to ~1e-3: in fp32 it
+// would carry 6e-5 of relative error, and the replayed step would drift from the eagerly launched one, whose lr_t the
+// host computes in double), leaves it beside the counter and advances the counter
+__global__ void adam_lr_kernel(int* t_dev, float lr, float b1, float b2) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const double t = (double)(t_dev[0] + 1);
+    const double lr_t = (double)lr * sqrt(1.0 - pow((double)b2, t)) / (1.0 - pow((double)b1, t));
+    ((float*)t_dev)[1] = (float)lr_t;
+    t_dev[0] += 1;
+}
+
+__global__ __launch_bounds__(256) void adam_dev_kernel(float* p, const float* g, float* m, float* v, size_t count, float b1,
+                                                       float b2, float eps, const int* t_dev) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= count) return;
-    const float t = (float)(*t_dev + 1);
-    const float lr_t = lr * sqrtf(1.f - powf(b2, t)) / (1.f - powf(b1, t));
+    const float lr_t = ((const float*)t_dev)[1];
     const float gi = g[i];
     const float mi = b1 * m[i] + (1.f - b1) * gi;
     const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
@@ -177,8 +186,6 @@ __global__ __launch_bounds__(256) void adam_dev_kernel(float* p, const float* g,
     v[i] = vi;
     p[i] = p[i] - lr_t * mi / (sqrtf(vi) + eps);
 }
-
-__global__ void counter_add_kernel(int* c, int inc) { if (threadIdx.x == 0 && blockIdx.x == 0) *c += inc; }
 
 // ---- layout / value conversion at the frame edge ------------------------------------------------------
 __global__ void u8_to_nchw_kernel(const uint8_t* src, float* dst, int n, int h, int w, int c) {
@@ -407,13 +414,13 @@ int vcg_adam_keras_multi_dev(float* p, const float* g, float* m, float* v, size_
                              float beta_2, float eps, int* t_dev, vcg_stream_t stream) {
     VCG_CHECK_PTR(p); VCG_CHECK_PTR(g); VCG_CHECK_PTR(m); VCG_CHECK_PTR(v); VCG_CHECK_PTR(t_dev);
     hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(adam_lr_kernel, dim3(1), dim3(64), 0, st, (int*)t_dev, lr, beta_1, beta_2);
+    VCG_LAUNCH_CHECK();
     if (count) {
-        hipLaunchKernelGGL(adam_dev_kernel, dim3(blocks_for(count)), dim3(256), 0, st, p, g, m, v, count, lr, beta_1,
-                           beta_2, eps, (const int*)t_dev);
+        hipLaunchKernelGGL(adam_dev_kernel, dim3(blocks_for(count)), dim3(256), 0, st, p, g, m, v, count, beta_1, beta_2, eps,
+                           (const int*)t_dev);
         VCG_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(counter_add_kernel, dim3(1), dim3(64), 0, st, t_dev, 1);
-    VCG_LAUNCH_CHECK();
     return VCG_OK;
 }
 

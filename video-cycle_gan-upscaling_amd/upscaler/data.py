@@ -51,3 +51,30 @@ def device_to_frames_u8(x_nchw):
     out = torch.empty((n, h, w, c), dtype=torch.uint8, device=rt.device)
     L.check(rt.lib.vcg_nchw_to_frames_u8(x_nchw.data_ptr(), out.data_ptr(), n, h, w, c, rt.stream), "vcg_nchw_to_frames_u8")
     return out
+
+
+def assemble_training_batch(cropped_hd, cropped_gen1, cropped_gen2, cropped_scaled):
+    """The batch assembly of the training loop on the device (upscaling/train_gan3.py:341-345): the loop concatenates the
+    three down-scaled variants of each crop into one low-res batch of 3B frames and repeats the high-res crops three times
+    (``pd.concat([hd, hd, hd])`` / ``pd.concat([gen1, gen2, scaled])``), then maps uint8 -> [-1, 1].
+
+    Arguments: uint8 NHWC stacks (numpy / torch / sequences of HxWx3 images) of B frames each.  Returns
+    (image_batch_lr, image_batch_hr): device fp32 NCHW tensors of 3B frames, ready for ``GanTrainer.train_step`` --
+    each uint8 frame crosses PCIe once (1 byte per sample instead of the loop's 8-byte float64 arrays), the value map and
+    the layout change run in vcg_frames_u8_to_nchw, and the three copies of the high-res frames are written by the device."""
+    rt = E.Runtime.get()
+
+    def stack(x):
+        if isinstance(x, torch.Tensor):
+            return x
+        return torch.from_numpy(np.ascontiguousarray(np.stack([np.asarray(f) for f in x]) if not isinstance(x, np.ndarray) else x))
+    hd, g1, g2, sc = (stack(v) for v in (cropped_hd, cropped_gen1, cropped_gen2, cropped_scaled))
+    if not (g1.shape == g2.shape == sc.shape) or hd.shape[0] != g1.shape[0]:
+        raise ValueError("the three low-res variants must share a shape and the batch size of the high-res crops")
+    lr = frames_u8_to_device(torch.cat([g1, g2, sc], 0))
+    hr1 = frames_u8_to_device(hd)
+    b = hr1.shape[0]
+    hr = rt.empty(3 * b, *hr1.shape[1:])
+    for i in range(3):
+        hr[i * b:(i + 1) * b].copy_(hr1)
+    return lr, hr

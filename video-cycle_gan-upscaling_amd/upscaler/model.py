@@ -37,8 +37,12 @@ class Adam:
         self.iterations = 0
 
     def lr_t(self):
+        """bias-corrected step size, evaluated in double on the float32 values of lr / beta_1 / beta_2 (the values the
+        kernels -- and Keras' float32 graph -- work with); vcg_adam_keras_multi_dev evaluates the same expression on the
+        device, so eagerly launched and graph-replayed steps agree bit for bit"""
         t = self.iterations + 1
-        return self.lr * math.sqrt(1.0 - self.beta_2 ** t) / (1.0 - self.beta_1 ** t)
+        lr, b1, b2 = (float(np.float32(v)) for v in (self.lr, self.beta_1, self.beta_2))
+        return lr * math.sqrt(1.0 - b2 ** t) / (1.0 - b1 ** t)
 
 
 _DEFAULT_ADAM = Adam()     # mirrors the reference's default-argument instance
@@ -836,7 +840,7 @@ class GanTrainer:
             raise NotImplementedError("graph capture needs a step without host reads inside")
         rt = self.rt
         if self._t_dev is None:
-            self._t_dev = torch.tensor([self.opt.iterations], dtype=torch.int32, device=rt.device)
+            self._t_dev = torch.tensor([self.opt.iterations, 0], dtype=torch.int32, device=rt.device)    # {t, lr_t scratch}
         self._g_lr, self._g_hr = lr.clone(), hr.clone()
         self.train_step(self._g_lr, self._g_hr)        # eager warm-up with the device-side counter (lazy buffers exist)
         torch.cuda.synchronize()
