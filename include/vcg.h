@@ -227,6 +227,14 @@ int vcg_pack_final9x9_bf16(const void* w, void* out, hipStream_t stream);
 int vcg_conv9x9_to3_bf16_fwd(const vcg_conv_desc* d, const void* x, const void* wfrag, const void* bias, int32_t tanh_act, void* y,
                              hipStream_t stream);
 
+/* initial/conv of the generator (upscaling/upscaler/model.py:275-276): Conv2D(64, 9, 'same') + bias + PReLU from the
+ * fp32 NCHW frames to bf16 NHWC -- the entry into the bf16 layout.  wfrag: VCG_FIRST9X9_WFRAG_BYTES bytes of MFMA operand
+ * fragments made by vcg_pack_first9x9_bf16 from Keras' (9,9,3,64) fp32 kernel; prelu_alpha may be NULL (no activation). */
+#define VCG_FIRST9X9_WFRAG_BYTES (27 * 64 * 2 * 16)
+int vcg_pack_first9x9_bf16(const void* w, void* out, hipStream_t stream);
+int vcg_conv9x9_from3_bf16_fwd(const vcg_conv_desc* d, const void* x, const void* wfrag, const void* bias, const void* prelu_alpha,
+                               void* y, hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -235,3 +235,29 @@ def test_bf16_generator_matches_oracle_predict(rt, res, n, h, w):
     u_got = np.around((got.astype(np.float64) + 1) * 127.5)
     report("bf16 generator uint8 frame difference: max %d levels, mean %.3f" % (np.abs(u_ref - u_got).max(), np.abs(u_ref - u_got).mean()))
     assert np.abs(u_ref - u_got).max() <= 6
+
+
+@pytest.mark.parametrize("n,h,w,prelu", [(2, 12, 32, True), (1, 13, 45, True), (2, 40, 72, False), (1, 5, 7, True)])
+def test_first_conv9x9_3to64_bf16(rt, n, h, w, prelu):
+    from oracle import keras_ops as K
+    from upscaler import _lib as L
+    g = torch.Generator().manual_seed(n * 1000 + h * 10 + w)
+    x = torch.rand(n, 3, h, w, generator=g) * 2 - 1
+    wk = torch.randn(9, 9, 3, 64, generator=g) * 0.1
+    b = torch.randn(64, generator=g) * 0.2
+    al = torch.rand(64, generator=g) * 0.5
+    xd, wd, bd, ad = (t.to(rt.device) for t in (x, wk, b, al))
+    wf = torch.empty(L.FIRST9X9_WFRAG_BYTES, dtype=torch.uint8, device=rt.device)
+    L.check(rt.lib.vcg_pack_first9x9_bf16(wd.data_ptr(), wf.data_ptr(), rt.stream), "pack_first")
+    y = torch.empty(n, h, w, 64, dtype=torch.bfloat16, device=rt.device)
+    d = L.ConvDesc(n, 3, h, w, 64, h, w, 9, 9, 1, 4, 4)
+    L.check(rt.lib.vcg_conv9x9_from3_bf16_fwd(ctypes.byref(d), xd.data_ptr(), wf.data_ptr(), bd.data_ptr(), ad.data_ptr() if prelu else None,
+                                              y.data_ptr(), rt.stream), "vcg_conv9x9_from3_bf16_fwd")
+    got = _to_nchw_f32(rt, y).cpu().double()
+    ref = K.conv2d(_bf16_round(x), _bf16_round(wk), b.double(), 1, "same")
+    if prelu:
+        ref = torch.clamp(ref, min=0) + al.double().view(1, -1, 1, 1) * torch.clamp(ref, max=0)
+    e = rel_err(got, ref)
+    ew = float(((got - ref).abs() / (ref.abs() * 2.0 ** -8 + 1e-3 * ref.abs().max())).max())
+    report("bf16 first conv9x9 3->64 n=%d %dx%d prelu=%s  err=%.2e  elementwise(ulp-scaled)=%.2f" % (n, h, w, prelu, e, ew))
+    assert e < TOL_BF16 and ew < 1.0

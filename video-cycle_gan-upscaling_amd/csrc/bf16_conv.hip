@@ -30,6 +30,16 @@ __device__ __forceinline__ void swap32(float& a, float& b) {
     b = __uint_as_float(sw.y);
 }
 
+// compile-time loop: f(std::integral_constant<int, 0>{}), ..., f(std::integral_constant<int, N-1>{})
+template <class F, int... Is>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Is...>) {
+    (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // layout / packing helpers
 // ---------------------------------------------------------------------------------------------------------------
@@ -320,6 +330,185 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_c64_bf16_kernel(C3Params p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// 9x9 stride-1 'same' convolution, 3 -> 64 channels (+bias, PReLU): the generator's initial/conv (model.py:275-276)
+// ---------------------------------------------------------------------------------------------------------------
+// Input: the fp32 NCHW frames as they arrive; output: bf16 NHWC, i.e. the kernel is also the entry into the bf16
+// layout.  In LDS a pixel is RGB0 in bf16 (8 bytes), so 4 consecutive pixels x 4 channels are one 16-wide k-step and
+// a lane's operand fragment (2 pixels) is one 8-byte-aligned ds_read2_b64: k-steps = 9 ky x 3 groups of 4 kx (the
+// taps kx = 9..11 carry zero weights) = 27, against 36 of the 64-channel 3x3 convolution.  Same skeleton as
+// conv3x3_c64_bf16_kernel: 6 compute + 2 loader waves, weights (54 KiB of operand fragments) resident in LDS,
+// 12x32-pixel tiles, permlane-swapped 16-byte stores.  The kernel is bound by its 128 bytes of output per pixel.
+constexpr int I_HR = TR + 8;                 // halo rows
+constexpr int I_HC = 44;                     // 32 + 8 halo columns + 3 (kx up to 11) + 1
+constexpr int I_ROWB = I_HC * 8;
+constexpr int I_XB = I_HR * I_ROWB;          // 7040 B
+constexpr int I_WB = 27 * 64 * 32;           // 55296 B: [k-step][out-channel][half][8 bf16]
+constexpr int I_NPIX = I_HR * I_HC;          // 880 pixels per halo tile
+constexpr int I_NPRE = (I_NPIX + NLW * 64 - 1) / (NLW * 64);      // 7 pixels per loader lane
+
+struct I9Params {
+    const float* x;          // fp32 NCHW [n][3][h][w]
+    const uint4* w;          // packed fragments (vcg_pack_first9x9_bf16)
+    const float* bias;       // [64] or null
+    const float* alpha;      // PReLU slopes [64] or null (none)
+    __bf16* y;               // bf16 NHWC [n][h][w][64]
+    int n, h, w_, tiles_x, tiles_y, total;
+};
+
+__global__ __launch_bounds__(NT, 1) void conv9x9_c3to64_bf16_kernel(I9Params p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* wl = smem;
+    unsigned char* xl = smem + I_WB;
+    float* prm = (float*)(smem + I_WB + I_XB);       // bias[64], slope[64]
+    const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, hh = lane >> 5;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    for (int c = tid; c < I_WB / 16; c += NT) ((uint4*)wl)[c] = p.w[c];
+    if (tid < 64) {
+        prm[tid] = p.bias ? p.bias[tid] : 0.f;
+        prm[64 + tid] = p.alpha ? p.alpha[tid] : 1.f;
+    }
+    const long plane = (long)p.h * p.w_;
+
+    if (wv >= NCW) {
+        const int lt = tid - NCW * 64;
+        float pre[I_NPRE][3];
+        auto fetch = [&](int tile) {
+            const int txi = tile % p.tiles_x, t2 = tile / p.tiles_x, tyi = t2 % p.tiles_y, img = t2 / p.tiles_y;
+            const int y0 = tyi * TR - 4, x0 = txi * TC - 4;
+            const float* xi = p.x + (long)img * 3 * plane;
+#pragma unroll
+            for (int i = 0; i < I_NPRE; ++i) {
+                const int pix = min(lt + NLW * 64 * i, I_NPIX - 1);
+                const int row = pix / I_HC, col = pix - row * I_HC;
+                const int gy = y0 + row, gx = x0 + col;
+                const bool ok = (unsigned)gy < (unsigned)p.h && (unsigned)gx < (unsigned)p.w_;
+                const long o = (long)min(max(gy, 0), p.h - 1) * p.w_ + min(max(gx, 0), p.w_ - 1);
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch) {
+                    const float v = xi[ch * plane + o];
+                    pre[i][ch] = ok ? v : 0.f;
+                }
+            }
+        };
+        auto stash = [&]() {
+#pragma unroll
+            for (int i = 0; i < I_NPRE; ++i) {
+                const int pix = min(lt + NLW * 64 * i, I_NPIX - 1);
+                bf16x4 v;
+                v[0] = (__bf16)pre[i][0];
+                v[1] = (__bf16)pre[i][1];
+                v[2] = (__bf16)pre[i][2];
+                v[3] = (__bf16)0.f;
+                *(bf16x4*)(xl + pix * 8) = v;
+            }
+        };
+        int tile = blockIdx.x;
+        fetch(tile);
+        stash();
+        lds_barrier();
+        for (; tile < p.total; tile += gridDim.x) {
+            const int next = tile + gridDim.x;
+            if (next < p.total) fetch(next);
+            lds_barrier();
+            if (next < p.total) stash();
+            lds_barrier();
+        }
+        return;
+    }
+
+    const int aoff = r * 32 + hh * 16;                         // weight fragment of (co = r [+32], half)
+    const unsigned char* xb = xl + (wv * 2) * I_ROWB + (r + 2 * hh) * 8;
+    lds_barrier();
+
+    for (int tile = blockIdx.x; tile < p.total; tile += gridDim.x) {
+        const int txi = tile % p.tiles_x, t2 = tile / p.tiles_x, tyi = t2 % p.tiles_y, img = t2 / p.tiles_y;
+        const int gx = txi * TC + r, gy0 = tyi * TR + wv * 2;
+        const bool okx = gx < p.w_;
+
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+
+        bf16x8 fa[2][2], fb[2][2];
+        auto frag = [&](auto ic) {
+            constexpr int i = decltype(ic)::value, ky = i / 3, j = i - 3 * ky, buf = i & 1;
+            const unsigned char* wa = wl + i * 2048 + aoff;
+            fa[buf][0] = *(const bf16x8*)(wa);
+            fa[buf][1] = *(const bf16x8*)(wa + 1024);
+            const unsigned char* b0 = xb + ky * I_ROWB + j * 32;
+            bf16x4 lo = *(const bf16x4*)(b0), hi = *(const bf16x4*)(b0 + 8);
+            fb[buf][0] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            lo = *(const bf16x4*)(b0 + I_ROWB);
+            hi = *(const bf16x4*)(b0 + I_ROWB + 8);
+            fb[buf][1] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        };
+        frag(std::integral_constant<int, 0>{});
+        static_for<27>([&](auto ic) {
+            constexpr int i = decltype(ic)::value, cur = i & 1;
+            if constexpr (i + 1 < 27) frag(std::integral_constant<int, i + 1>{});
+            __builtin_amdgcn_sched_barrier(0);
+            acc[0][0] = mfma_bf16(fa[cur][0], fb[cur][0], acc[0][0]);
+            acc[0][1] = mfma_bf16(fa[cur][0], fb[cur][1], acc[0][1]);
+            acc[1][0] = mfma_bf16(fa[cur][1], fb[cur][0], acc[1][0]);
+            acc[1][1] = mfma_bf16(fa[cur][1], fb[cur][1], acc[1][1]);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        lds_barrier();
+
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int co = mt * 32 + 16 * q + 8 * hh;
+                float sh[8], al[8];
+                *(f32x4*)&sh[0] = *(const f32x4*)(prm + co);
+                *(f32x4*)&sh[4] = *(const f32x4*)(prm + co + 4);
+                *(f32x4*)&al[0] = *(const f32x4*)(prm + 64 + co);
+                *(f32x4*)&al[4] = *(const f32x4*)(prm + 64 + co + 4);
+#pragma unroll
+                for (int pt = 0; pt < 2; ++pt) {
+                    float v[8];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float lo = acc[mt][pt][8 * q + j], hi = acc[mt][pt][8 * q + 4 + j];
+                        swap32(lo, hi);
+                        v[j] = lo;
+                        v[4 + j] = hi;
+                    }
+                    bf16x8 ov;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float u = v[j] + sh[j];
+                        ov[j] = (__bf16)(u >= 0.f ? u : u * al[j]);
+                    }
+                    const int gy = gy0 + pt;
+                    if (gy < p.h && okx) *(bf16x8*)(p.y + ((long)(img * p.h + gy) * p.w_ + gx) * 64 + co) = ov;
+                }
+            }
+        lds_barrier();
+    }
+}
+
+__global__ void pack_first9x9_kernel(const float* __restrict__ w, uint4* __restrict__ out) {
+    // w: Keras (9,9,3,64) -> out[k-step = ky*3+j][co][half] = 8 bf16: (kx = 4j+2*half, RGB0), (kx+1, RGB0)
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= 27 * 64 * 2) return;
+    const int h = idx & 1, co = (idx >> 1) & 63, ks = idx >> 7, ky = ks / 3, j = ks - 3 * ky;
+    bf16x8 v;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int kx = 4 * j + 2 * h + (e >> 2), c = e & 3;
+        v[e] = (__bf16)((kx < 9 && c < 3) ? w[((ky * 9 + kx) * 3 + c) * 64 + co] : 0.f);
+    }
+    out[idx] = __builtin_bit_cast(uint4, v);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // 3x3 stride-2 'same' transposed convolution, 64 -> 64*m channels (+LeakyReLU): upsampling_block (model.py:70-75)
 // ---------------------------------------------------------------------------------------------------------------
 // TF 'same' with k=3, s=2 crops nothing at the top/left: out[o] = sum_i x[i] w[o-2i]  =>  the four sub-pixel phases
@@ -351,14 +540,6 @@ __host__ __device__ constexpr int ct_phase(int t) { return t < 4 ? 0 : t < 6 ? 1
 __host__ __device__ constexpr bool ct_first(int t) { return t == 0 || t == 4 || t == 6 || t == 8; }
 __host__ __device__ constexpr bool ct_last(int t) { return t == 3 || t == 5 || t == 7 || t == 8; }
 
-template <class F, int... Is>
-__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Is...>) {
-    (f(std::integral_constant<int, Is>{}), ...);
-}
-template <int N, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-    static_for_impl(f, std::make_integer_sequence<int, N>{});
-}
 
 __global__ __launch_bounds__(NT, 1) void convt3x3_c64_bf16_kernel(CTParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -854,6 +1035,47 @@ int vcg_conv9x9_to3_bf16_fwd(const vcg_conv_desc* d, const void* x, const void* 
     }
     const int grid = p.total < 512 ? p.total : 512;
     conv9x9_c256to3_bf16_kernel<<<grid, 256, F_LDS, stream>>>(p);
+    VCG_LAUNCH_CHECK();
+    return VCG_OK;
+}
+
+int vcg_pack_first9x9_bf16(const void* w, void* out, hipStream_t stream) {
+    VCG_CHECK_PTR(w);
+    VCG_CHECK_PTR(out);
+    pack_first9x9_kernel<<<(27 * 64 * 2 + 255) / 256, 256, 0, stream>>>((const float*)w, (uint4*)out);
+    VCG_LAUNCH_CHECK();
+    return VCG_OK;
+}
+
+int vcg_conv9x9_from3_bf16_fwd(const vcg_conv_desc* d, const void* x, const void* wfrag, const void* bias, const void* prelu_alpha,
+                               void* y, hipStream_t stream) {
+    VCG_CHECK_PTR(d);
+    VCG_CHECK_PTR(x);
+    VCG_CHECK_PTR(wfrag);
+    VCG_CHECK_PTR(y);
+    if (d->n <= 0 || d->h <= 0 || d->w <= 0 || d->oh != d->h || d->ow != d->w) return VCG_E_SHAPE;
+    if (d->cin != 3 || d->cout != 64 || d->kh != 9 || d->kw != 9 || d->stride != 1 || d->pad_top != 4 || d->pad_left != 4) return VCG_E_UNSUPPORTED;
+    I9Params p;
+    p.x = (const float*)x;
+    p.w = (const uint4*)wfrag;
+    p.bias = (const float*)bias;
+    p.alpha = (const float*)prelu_alpha;
+    p.y = (__bf16*)y;
+    p.n = d->n;
+    p.h = d->h;
+    p.w_ = d->w;
+    p.tiles_x = ceil_div(d->w, TC);
+    p.tiles_y = ceil_div(d->h, TR);
+    p.total = p.n * p.tiles_x * p.tiles_y;
+    const int lds = I_WB + I_XB + 512;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)conv9x9_c3to64_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    const int grid = p.total < 512 ? p.total : 512;        // 62 KiB of LDS: two workgroups per CU
+    conv9x9_c3to64_bf16_kernel<<<grid, NT, lds, stream>>>(p);
     VCG_LAUNCH_CHECK();
     return VCG_OK;
 }

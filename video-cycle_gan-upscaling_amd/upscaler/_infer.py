@@ -6,14 +6,14 @@ upscale_factor 2 -- the topology BASELINE.json's configs name.  What the referen
 ``upscaler.predict(batch)`` (upscaling/upscaler/data.py:358-363, train_gan3.py:346): a forward pass with the
 BatchNormalization layers in inference mode.  Here that pass is
 
-    initial/conv 9x9 3->64 + PReLU            fp32 kernel (3 input channels), output re-laid out to bf16 NHWC
+    initial/conv 9x9 3->64 + PReLU            vcg_conv9x9_from3_bf16_fwd (fp32 NCHW frames in, bf16 NHWC out)
     res blocks: conv 3x3 + BN + PReLU         vcg_conv2d_bf16_fwd, BN folded into the epilogue's scale/shift
                 conv 3x3 + BN + Add           same kernel, residual operand = block input
     prefinal conv 3x3 + BN + Add(long skip)   same kernel
     upsampling: ConvT 3x3 s2 64->256 + LReLU  vcg_conv_transpose2d_bf16_fwd
     final/conv 9x9 256->3 + tanh              vcg_conv9x9_to3_bf16_fwd (fp32 NCHW out)
 
-23 launches, recorded once per input shape into a hipGraph and replayed per batch.  Activations are bf16 NHWC,
+22 launches, recorded once per input shape into a hipGraph and replayed per batch.  Activations are bf16 NHWC,
 accumulation and the epilogue arithmetic fp32; the weights are rounded to bf16 once, when the engine is built or
 ``refresh()`` is called after a weight update.  The folded BatchNormalization parameters
 (scale = gamma / sqrt(moving_var + 1e-3), shift = (bias - moving_mean) * scale + beta) are 64-element fp32 vectors
@@ -79,15 +79,19 @@ class Bf16Generator:
         L.check(rt.lib.vcg_pack_final9x9_bf16(m.c_fin.ps[m.c_fin.name + "/kernel"].data_ptr(), wf.data_ptr(), rt.stream),
                 "vcg_pack_final9x9_bf16")
         self.final = (wf, m.c_fin.ps[m.c_fin.name + "/bias"])
+        w0 = torch.empty(L.FIRST9X9_WFRAG_BYTES, dtype=torch.uint8, device=rt.device)
+        L.check(rt.lib.vcg_pack_first9x9_bf16(m.c_init.ps[m.c_init.name + "/kernel"].data_ptr(), w0.data_ptr(), rt.stream),
+                "vcg_pack_first9x9_bf16")
+        self.first = (w0, m.c_init.ps[m.c_init.name + "/bias"], m.c_init.ps[m.a_init.prelu_name + "/alpha"])
         self._graphs.clear()          # recorded graphs hold the old parameter buffers
 
-    # ---- one forward pass (23 launches) -----------------------------------------------------------------------
+    # ---- one forward pass (22 launches) -----------------------------------------------------------------------
     def _buffers(self, n, h, w):
         key = (n, h, w)
         if key not in self._bufs:
             dev = self.rt.device
             bf = lambda c, hh, ww: torch.empty(n, hh, ww, c, dtype=torch.bfloat16, device=dev)
-            self._bufs[key] = {"t0": torch.empty(n, 64, h, w, dtype=torch.float32, device=dev), "skip": bf(64, h, w),
+            self._bufs[key] = {"skip": bf(64, h, w),
                                "a": bf(64, h, w), "b": bf(64, h, w), "c": bf(64, h, w), "u": bf(256, 2 * h, 2 * w),
                                "y": torch.empty(n, 3, 2 * h, 2 * w, dtype=torch.float32, device=dev)}
         return self._bufs[key]
@@ -105,12 +109,10 @@ class Bf16Generator:
         rt, m = self.rt, self.model
         n, _, h, w = x.shape
         B = self._buffers(n, h, w)
-        ci = m.c_init
-        d0 = ci.desc(n, h, w)
-        ep0 = L.Epilogue(ci.ps[ci.name + "/bias"].data_ptr(), L.ACT_PRELU, 0.0, ci.ps[m.a_init.prelu_name + "/alpha"].data_ptr(), None)
-        L.check(rt.lib.vcg_conv2d_fwd(ctypes.byref(d0), x.data_ptr(), ci.ps[ci.name + "/kernel"].data_ptr(), B["t0"].data_ptr(),
-                                      ctypes.byref(ep0), rt.stream), "vcg_conv2d_fwd[initial]")
-        L.check(rt.lib.vcg_f32_nchw_to_bf16_nhwc(B["t0"].data_ptr(), B["skip"].data_ptr(), n, 64, h, w, rt.stream), "to_bf16")
+        w0, b0, a0 = self.first
+        d0 = L.ConvDesc(n, 3, h, w, 64, h, w, 9, 9, 1, 4, 4)
+        L.check(rt.lib.vcg_conv9x9_from3_bf16_fwd(ctypes.byref(d0), x.data_ptr(), w0.data_ptr(), b0.data_ptr(), a0.data_ptr(),
+                                                  B["skip"].data_ptr(), rt.stream), "vcg_conv9x9_from3_bf16_fwd")
         cur = B["skip"]                     # block input; outputs ping-pong between "a" and "c", "skip" is never overwritten
         for (w1, s1, h1, al, w2, s2, h2) in self.trunk:
             out = B["a"] if cur is not B["a"] else B["c"]

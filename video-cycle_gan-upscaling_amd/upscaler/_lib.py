@@ -27,6 +27,7 @@ class Epilogue(ctypes.Structure):
 
 
 FINAL9X9_WFRAG_BYTES = (4 * 9 * 4 * 64 + 4) * 16      # VCG_FINAL9X9_WFRAG_BYTES
+FIRST9X9_WFRAG_BYTES = 27 * 64 * 2 * 16                # VCG_FIRST9X9_WFRAG_BYTES
 
 
 class EpilogueBf16(ctypes.Structure):
@@ -84,6 +85,8 @@ SIGNATURES = {
     "vcg_bf16_nhwc_to_f32_nchw": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
     "vcg_conv2d_bf16_fwd": (c_int, [_D, _P, _P, _P, _EB, _P]),
     "vcg_conv_transpose2d_bf16_fwd": (c_int, [_D, _P, _P, _P, _EB, _P]),
+    "vcg_pack_first9x9_bf16": (c_int, [_P, _P, _P]),
+    "vcg_conv9x9_from3_bf16_fwd": (c_int, [_D, _P, _P, _P, _P, _P, _P]),
     "vcg_pack_final9x9_bf16": (c_int, [_P, _P, _P]),
     "vcg_conv9x9_to3_bf16_fwd": (c_int, [_D, _P, _P, _P, c_int, _P, _P]),
 }
