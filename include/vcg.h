@@ -151,12 +151,6 @@ int vcg_fill(float* y, size_t count, float value, vcg_stream_t stream);
 /* y = a*x + b*y */
 int vcg_axpby(const float* x, float* y, size_t count, float a, float b, vcg_stream_t stream);
 
-/* predict path (learning phase 0): BatchNormalization with moving statistics (upscaling/upscaler/model.py:20,23,284) folded
- * into the Conv2D in front of it.  w: (kh,kw,in,out) viewed as [rows = kh*kw*in][cout]; scale/shift: the per-channel affine
- * vcg_norm_finalize derives from the moving statistics; w_out = w * scale[co], bias_out = bias * scale + shift. */
-int vcg_fold_bn_into_conv(const float* w, const float* bias, const float* scale, const float* shift, size_t rows, int cout,
-                          float* w_out, float* bias_out, vcg_stream_t stream);
-
 /* MaxPooling2D((2,2), strides (2,2), 'valid') of the VGG19 feature extractor behind VGG_LOSS / VGG_MSE_LOSS /
  * VGG_MAE_LOSS (upscaling/upscaler/model.py:101-157; keras.applications.VGG19 block{1..4}_pool).  fp32 NCHW;
  * y: [n,c,h/2,w/2] (floor).  bwd: gradient to the first maximal element of each window (row-major), x = forward input. */

@@ -236,15 +236,6 @@ __global__ void nchw_to_nhwc_kernel(const float* src, float* dst, int n, int h, 
     dst[i] = src[((nn * c + ch) * h + y) * w + x];
 }
 
-// inference-mode BatchNormalization folded into the convolution in front of it: w'[r][co] = w[r][co] * scale[co],
-// b' = b * scale + shift  (scale / shift as vcg_norm_finalize derives them from the moving statistics)
-__global__ void fold_bn_kernel(const float* __restrict__ w, const float* __restrict__ b, const float* __restrict__ scale,
-                               const float* __restrict__ shift, size_t rows, int cout, float* __restrict__ wo, float* __restrict__ bo) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < rows * cout) wo[i] = w[i] * scale[i % cout];
-    if (i < (size_t)cout) bo[i] = (b ? b[i] : 0.f) * scale[i] + shift[i];
-}
-
 // MaxPooling2D((2,2), strides (2,2), 'valid') of keras.applications.VGG19 (the perceptual losses, model.py:101-157)
 __global__ void maxpool2x2_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, size_t planes, int h, int w) {
     const int oh = h >> 1, ow = w >> 1;
@@ -492,16 +483,6 @@ int vcg_maxpool2x2_bwd(const float* x, const float* dy, float* dx, int n, int c,
     if (n <= 0 || c <= 0 || h < 2 || w < 2) return VCG_E_SHAPE;
     const size_t total = (size_t)n * c * h * w;
     hipLaunchKernelGGL(maxpool2x2_bwd_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, x, dy, dx, (size_t)n * c, h, w);
-    VCG_LAUNCH_CHECK();
-    return VCG_OK;
-}
-
-int vcg_fold_bn_into_conv(const float* w, const float* bias, const float* scale, const float* shift, size_t rows, int cout,
-                          float* w_out, float* bias_out, vcg_stream_t stream) {
-    VCG_CHECK_PTR(w); VCG_CHECK_PTR(scale); VCG_CHECK_PTR(shift); VCG_CHECK_PTR(w_out); VCG_CHECK_PTR(bias_out);
-    if (rows == 0 || cout <= 0) return VCG_E_SHAPE;
-    hipLaunchKernelGGL(fold_bn_kernel, dim3(blocks_for(rows * cout)), dim3(256), 0, (hipStream_t)stream, w, bias, scale, shift, rows, cout,
-                       w_out, bias_out);
     VCG_LAUNCH_CHECK();
     return VCG_OK;
 }

@@ -524,31 +524,6 @@ def to_nhwc(rt, t):
     return out
 
 
-def conv_bn_infer(rt, conv, norm, x, residual=None, tag=None):
-    """predict path of Conv2D -> BatchNormalization(moving statistics) -> [PReLU | LeakyReLU] -> [+ residual] as ONE
-    convolution: the normalisation is folded into a scratch copy of the kernel and bias (vcg_fold_bn_into_conv), the
-    activation and the Add ride in the convolution's epilogue -- the separate pass over the activation tensor is gone."""
-    ps = conv.ps
-    c = conv.cout
-    scale, shift, invstd = rt.empty(c), rt.empty(c), rt.empty(c)
-    L.check(rt.lib.vcg_norm_finalize(ps[norm.name + "/moving_mean"].data_ptr(), ps[norm.name + "/moving_variance"].data_ptr(),
-                                     ps[norm.name + "/gamma"].data_ptr(), ps[norm.name + "/beta"].data_ptr(), c, 1, BN_EPS,
-                                     scale.data_ptr(), shift.data_ptr(), invstd.data_ptr(), None, None, 0.0, 0, rt.stream),
-            "vcg_norm_finalize")
-    wf, bf = rt.empty(conv.k, conv.k, conv.cin, c), rt.empty(c)
-    L.check(rt.lib.vcg_fold_bn_into_conv(ps[conv.name + "/kernel"].data_ptr(), ps[conv.name + "/bias"].data_ptr(), scale.data_ptr(),
-                                         shift.data_ptr(), conv.k * conv.k * conv.cin, c, wf.data_ptr(), bf.data_ptr(), rt.stream),
-            "vcg_fold_bn_into_conv")
-    n, _, h, w = x.shape
-    d = conv.desc(n, h, w)
-    y = rt.empty(n, c, d.oh, d.ow)
-    ep = L.Epilogue(bf.data_ptr(), norm.act, float(norm.alpha), norm._alpha_ptr(), _ptr(residual))
-    with Timed(rt, tag):
-        L.check(rt.lib.vcg_conv2d_fwd(ctypes.byref(d), x.data_ptr(), wf.data_ptr(), y.data_ptr(), ctypes.byref(ep), rt.stream),
-                "vcg_conv2d_fwd[%s+bn]" % conv.name)
-    return y
-
-
 def maxpool2x2(rt, x):
     """MaxPooling2D((2,2)) forward: fp32 NCHW -> [n,c,h//2,w//2]"""
     n, c, h, w = x.shape

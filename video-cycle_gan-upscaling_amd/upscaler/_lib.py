@@ -77,7 +77,6 @@ SIGNATURES = {
     "vcg_nchw_to_frames_u8": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
     "vcg_nhwc_to_nchw": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
     "vcg_nchw_to_nhwc": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
-    "vcg_fold_bn_into_conv": (c_int, [_P, _P, _P, _P, c_size_t, c_int, _P, _P, _P]),
     "vcg_maxpool2x2_fwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
     "vcg_maxpool2x2_bwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     # bf16-storage path

@@ -437,24 +437,7 @@ class UpscalerOrig(Model):
         from ._infer import Bf16Generator
         return Bf16Generator(self)
 
-    def _forward_predict_folded(self, x):
-        """learning phase 0 with BatchNormalization folded into the convolutions (no tape: nothing trains here)"""
-        rt = self.rt
-        h, _ = self.c_init.forward(x)
-        h, _ = self.a_init.forward(h, False)
-        skip = h
-        for (c1, n1, c2, n2) in self.blocks:
-            t = E.conv_bn_infer(rt, c1, n1, h, None, tag="trunk_conv")
-            h = E.conv_bn_infer(rt, c2, n2, t, h, tag="trunk_conv")
-        h = E.conv_bn_infer(rt, self.c_pre, self.n_pre, h, skip, tag="trunk_conv")
-        for u in self.ups:
-            h, _ = u.forward(h, tag="convt")
-        h, _ = self.c_fin.forward(h, tag="final_conv")
-        return h, None
-
     def forward(self, x, training):
-        if not training and self.n_pre.norm == "batch":
-            return self._forward_predict_folded(x)
         tape = []
         h, c = self.c_init.forward(x); tape.append(c)
         h, c = self.a_init.forward(h, training); tape.append(c)
