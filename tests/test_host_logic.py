@@ -106,7 +106,9 @@ def test_host_side_losses_and_optimizer():
             assert abs(g - fd) < 1e-6, (name, x)
     assert PM.wasserstein_loss(np.array([1, -1]), np.array([[2.0], [4.0]])) == -1.0
     a = PM.Adam()
-    assert abs(a.lr_t() - 1e-3 * math.sqrt(1 - 0.999) / (1 - 0.9)) < 1e-15
+    f32 = lambda v: float(np.float32(v))        # lr_t is evaluated on the float32 values the kernels (and Keras' graph) use
+    assert abs(a.lr_t() - f32(1e-3) * math.sqrt(1 - f32(0.999)) / (1 - f32(0.9))) < 1e-15
+    assert abs(a.lr_t() - 1e-3 * math.sqrt(1 - 0.999) / (1 - 0.9)) < 1e-7 * a.lr_t() * 1e3
     assert PM._content_kind("mean_squared_error") == "mse" and PM._content_kind(PM.PixelLoss("mae").loss) == "mae"
     with pytest.raises(NotImplementedError):
         PM._content_kind(lambda a, b: 0)
