@@ -60,6 +60,9 @@ CONV_CASES = [
     (128, 256, 4, 2, 1, 2, 32, 32),
     (3, 64, 4, 2, 1, 2, 64, 64),
     (256, 3, 9, 1, "same", 2, 40, 72),
+    (256, 3, 9, 1, "same", 1, 20, 64),       # width % 64 == 0: the row-chain kernel (conv_rowchain.hip)
+    (256, 3, 9, 1, "same", 2, 70, 128),      # two strips, several row segments
+    (256, 1, 9, 1, "same", 1, 9, 64),
 ]
 
 
@@ -296,3 +299,18 @@ def test_assemble_training_batch_matches_loop_body(rt):
     ref_lr = PD.convert_image_series_to_array(list(g1) + list(g2) + list(sc))
     assert np.array_equal(lr.permute(0, 2, 3, 1).cpu().numpy(), ref_lr.astype(np.float32))
     assert np.array_equal(hr.permute(0, 2, 3, 1).cpu().numpy(), ref_hr.astype(np.float32))
+
+
+def test_final_conv_rowchain_tanh(rt):
+    """final/conv with its fused tanh at a width the row-chain kernel serves (256 -> 3, 9x9, w % 64 == 0)"""
+    from upscaler import _engine as E, _lib as L
+    from oracle import keras_ops as K
+    layer = E.Conv2D("c", 256, 3, 9, 1, "same", L.ACT_TANH)
+    ps, wd = _standalone(rt, layer, seed=5)
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 256, 37, 128, generator=g, dtype=torch.float64) * 0.3
+    yr = torch.tanh(K.conv2d(x, wd["c/kernel"], wd["c/bias"], 1, "same"))
+    y, _ = layer.forward(x.float().to(rt.device))
+    e = rel_err(y, yr)
+    report("final conv (row-chain kernel) + tanh 256->3 n=2 37x128 fwd=%.2e" % e)
+    assert e < TOL

@@ -531,6 +531,10 @@ int launch_smallm(ConvParams p, hipStream_t st) {
 
 }  // namespace
 
+// conv_rowchain.hip: 9x9, 256 -> <=3 channels, width % 64 == 0 (the generator's final/conv); VCG_E_UNSUPPORTED otherwise
+int vcg_internal_conv9_rowchain(const float* x, const float* w, float* y, int n, int cin, int h, int wd, int cout, const float* bias, int act,
+                                int ws_t, int ws_m, int ws_k, hipStream_t st);
+
 // Generic entry used by the C ABI wrappers in api.hip.  Weight tensor w is [T][cin][cout] with cout
 // contiguous (or addressed by ws_* strides for the small-M kernel).
 int vcg_internal_conv(const float* x, const float* w, float* y, int n, int cin, int h, int wd, int cout,
@@ -550,6 +554,10 @@ int vcg_internal_conv(const float* x, const float* w, float* y, int n, int cin, 
     if (n <= 0 || cin <= 0 || cout <= 0 || oh <= 0 || ow <= 0) return VCG_E_SHAPE;
     if (smallm) {
         if (stride != 1 || cout * kw > 32) return VCG_E_UNSUPPORTED;
+        if (kh == 9 && kw == 9 && !flip && pad_top == 4 && pad_left == 4 && oh == h && ow == wd && !p.prelu && !p.residual) {
+            const int rc = vcg_internal_conv9_rowchain(x, w, y, n, cin, h, wd, cout, p.bias, p.act, ws_t, ws_m, ws_k, st);
+            if (rc != VCG_E_UNSUPPORTED) return rc;
+        }
         if (kh == 9 && kw == 9) return launch_smallm<9, 9, 8>(p, st);
         if (kh == 4 && kw == 4) return launch_smallm<4, 4, 8>(p, st);
         if (kh == 3 && kw == 3) return launch_smallm<3, 3, 8>(p, st);

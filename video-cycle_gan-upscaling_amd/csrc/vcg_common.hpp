@@ -30,7 +30,7 @@ __device__ __forceinline__ float apply_act(float v, int act, float alpha) {
 
 // A readable zero for "optional pointer is NULL": lets epilogues load bias / slope unconditionally
 // (pointer and index are selected with scalar ops) instead of branching around every load.
-__device__ const float vcg_zero_word[4] = {0.f, 0.f, 0.f, 0.f};
+__device__ __attribute__((aligned(16))) const float vcg_zero_word[4] = {0.f, 0.f, 0.f, 0.f};
 
 // wave64 sum via DPP-free shuffles
 __device__ __forceinline__ float wave_sum(float v) {
