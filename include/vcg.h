@@ -235,6 +235,16 @@ int vcg_pack_first9x9_bf16(const void* w, void* out, hipStream_t stream);
 int vcg_conv9x9_from3_bf16_fwd(const vcg_conv_desc* d, const void* x, const void* wfrag, const void* bias, const void* prelu_alpha,
                                void* y, hipStream_t stream);
 
+/* BatchNormalization / instance norm (+PReLU / LeakyReLU, +Add) on bf16 NHWC activations (model.py:20-25): statistics
+ * and arithmetic in fp32.  vcg_norm_stats_bf16: per-channel (VCG_NORM_BATCH) or per-(n,c) (VCG_NORM_INSTANCE) mean and
+ * biased variance, c % 8 == 0, c <= 256; feed them to vcg_norm_finalize (shared with the fp32 path) for scale / shift and
+ * the moving averages, then vcg_norm_act_fwd_bf16: y = act(x*scale + shift) + residual, scale/shift [c] or [n*c]. */
+size_t vcg_norm_stats_bf16_workspace_bytes(int n, int c, int hw, int mode);
+int vcg_norm_stats_bf16(const void* x, int n, int c, int hw, int mode, float* mean, float* var, void* ws, size_t ws_bytes,
+                        hipStream_t stream);
+int vcg_norm_act_fwd_bf16(const void* x, int n, int c, int hw, const float* scale, const float* shift, int per_sample, int act,
+                          float alpha, const float* prelu_alpha, const void* residual, void* y, hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

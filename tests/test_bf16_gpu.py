@@ -261,3 +261,66 @@ def test_first_conv9x9_3to64_bf16(rt, n, h, w, prelu):
     ew = float(((got - ref).abs() / (ref.abs() * 2.0 ** -8 + 1e-3 * ref.abs().max())).max())
     report("bf16 first conv9x9 3->64 n=%d %dx%d prelu=%s  err=%.2e  elementwise(ulp-scaled)=%.2f" % (n, h, w, prelu, e, ew))
     assert e < TOL_BF16 and ew < 1.0
+
+
+@pytest.mark.parametrize("mode,n,c,h,w,act,residual", [("batch", 3, 64, 9, 13, "prelu", True), ("instance", 2, 64, 50, 47, "none", True),
+                                                      ("instance", 2, 128, 7, 5, "lrelu", False), ("batch", 2, 256, 40, 60, "prelu", False)])
+def test_norm_bf16(rt, mode, n, c, h, w, act, residual):
+    """bf16 NHWC statistics (+ the fp32 finalize) and normalise + activation + Add against fp64 on the same bf16 values"""
+    from upscaler import _engine as E, _lib as L
+    g = torch.Generator().manual_seed(c + h)
+    x = torch.randn(n, c, h, w, generator=g) * 1.7 + torch.randn(1, c, 1, 1, generator=g) * 3.0      # |mean| ~ std: the shift matters
+    res = torch.randn(n, c, h, w, generator=g) if residual else None
+    gamma, beta = torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g) * 0.2
+    alpha = torch.rand(c, generator=g) * 0.4
+    xd = _to_nhwc_bf16(rt, x.to(rt.device))
+    rows = n if mode == "instance" else 1
+    code = L.NORM_INSTANCE if mode == "instance" else L.NORM_BATCH
+    mean, var, scale, shift, invstd = (torch.empty(rows * c, device=rt.device) for _ in range(5))
+    ws, wsn = rt.workspace(rt.lib.vcg_norm_stats_bf16_workspace_bytes(n, c, h * w, code))
+    L.check(rt.lib.vcg_norm_stats_bf16(xd.data_ptr(), n, c, h * w, code, mean.data_ptr(), var.data_ptr(), ws, wsn, rt.stream), "stats")
+    xb = _bf16_round(x)
+    dims = (2, 3) if mode == "instance" else (0, 2, 3)
+    mref, vref = xb.mean(dims), xb.var(dims, unbiased=False)
+    e_m, e_v = rel_err(mean.cpu().view(mref.shape), mref), rel_err(var.cpu().view(vref.shape), vref)
+    gd, bd, ad = gamma.to(rt.device), beta.to(rt.device), alpha.to(rt.device)
+    eps = E.IN_EPS if mode == "instance" else E.BN_EPS
+    L.check(rt.lib.vcg_norm_finalize(mean.data_ptr(), var.data_ptr(), None if mode == "instance" else gd.data_ptr(),
+                                     None if mode == "instance" else bd.data_ptr(), c, rows, eps, scale.data_ptr(), shift.data_ptr(),
+                                     invstd.data_ptr(), None, None, 0.0, 0, rt.stream), "finalize")
+    rd = _to_nhwc_bf16(rt, res.to(rt.device)) if residual else None
+    y = torch.empty_like(xd)
+    L.check(rt.lib.vcg_norm_act_fwd_bf16(xd.data_ptr(), n, c, h * w, scale.data_ptr(), shift.data_ptr(), 1 if mode == "instance" else 0,
+                                         {"none": L.ACT_NONE, "prelu": L.ACT_PRELU, "lrelu": L.ACT_LRELU}[act], 0.2,
+                                         ad.data_ptr() if act == "prelu" else None, rd.data_ptr() if residual else None, y.data_ptr(),
+                                         rt.stream), "norm_act")
+    got = _to_nchw_f32(rt, y).cpu().double()
+    shp = (n, c, 1, 1) if mode == "instance" else (1, c, 1, 1)
+    ref = (xb - mref.view(shp)) / torch.sqrt(vref.view(shp) + eps)
+    if mode == "batch":
+        ref = ref * gamma.double().view(1, c, 1, 1) + beta.double().view(1, c, 1, 1)
+    if act == "prelu":
+        ref = torch.clamp(ref, min=0) + alpha.double().view(1, c, 1, 1) * torch.clamp(ref, max=0)
+    elif act == "lrelu":
+        ref = torch.where(ref > 0, ref, 0.2 * ref)
+    if residual:
+        ref = ref + _bf16_round(res)
+    e = rel_err(got, ref)
+    report("bf16 norm %s n=%d c=%d %dx%d act=%s res=%s  mean err=%.1e var err=%.1e out err=%.2e" % (mode, n, c, h, w, act, residual, e_m, e_v, e))
+    assert e_m < 1e-5 and e_v < 1e-4 and e < TOL_BF16          # fp32 sums of squares over up to 1e5 bf16 samples
+
+
+def test_bf16_generator_instance_norm(rt):
+    """norm='instance' generator (north_star's instance-norm variant) through the bf16 engine: per-image statistics on bf16"""
+    from oracle import models as M
+    from upscaler import model as PM
+    n, h, w, res = 2, 24, 40, 2
+    G = PM.make_upscaler_orig((2 * h, 2 * w, 3), kernel_size=3, upscale_factor=2, res_block_num=res, norm="instance", seed=7)
+    wd = _randomize_bn(G, 3)
+    x = (np.random.RandomState(1).randint(0, 256, (n, h, w, 3)) / 127.5 - 1).astype(np.float32)
+    with torch.no_grad():
+        ref, _ = M.upscaler_orig_forward(M.to_torch(wd, torch.float64), torch.tensor(x, dtype=torch.float64), False, res, 2, norm="instance")
+    got = G.to_inference_bf16().predict(x)
+    e = rel_err(got, ref.numpy())
+    report("bf16 generator (instance norm) predict res=%d n=%d %dx%d  err=%.2e" % (res, n, h, w, e))
+    assert e < 3e-2

@@ -380,3 +380,30 @@ def test_c4_frame_size_train_step_runs(rt):
     report("C4 frame size 540x960->1080x1920: band parity err=%.2e  train-step losses %s" % (e, ["%.4g" % v for v in losses]))
     assert e < TOL
     assert all(np.isfinite(v) for v in losses)
+
+
+def test_trainer_state_roundtrip_resumes_bit_exactly(rt, tmp_path):
+    """save_state after one step, keep training; a fresh trainer that loads the state reproduces the next step bit
+    for bit (weights, Adam moments, shared iteration counter)"""
+    from upscaler import model as PM, _engine as E
+
+    def make():
+        G = PM.make_upscaler_orig((64, 64, 3), kernel_size=3, upscale_factor=2, res_block_num=1, seed=7)
+        D = PM.make_discriminator_patchgan_70((64, 64, 3), seed=11)
+        _, _, gan = PM.make_and_compile_gan2(G, D, (32, 32, 3), (64, 64, 3), "mse", 1.0, lambda: PM.WassersteinLosses(), 1e-2,
+                                             optimizer=PM.Adam())
+        return G, D, gan.trainer
+    lr = [E.to_device_nchw(rt, _frames(20 + i, 2, 32, 32)) for i in range(2)]
+    hr = [E.to_device_nchw(rt, _frames(30 + i, 2, 64, 64)) for i in range(2)]
+    G1, D1, t1 = make()
+    t1.train_step(lr[0], hr[0])
+    path = str(tmp_path / "trainer.safetensors")
+    t1.save_state(path)
+    a = t1.train_step(lr[1], hr[1])
+    G2, D2, t2 = make()
+    t2.load_state(path)
+    assert t2.opt.iterations == 2
+    b = t2.train_step(lr[1], hr[1])
+    assert a == b
+    assert torch.equal(G1.ps.params, G2.ps.params) and torch.equal(D1.ps.params, D2.ps.params)
+    assert torch.equal(t1.g_slots.v, t2.g_slots.v) and torch.equal(t1.d_slots.m, t2.d_slots.m)

@@ -38,8 +38,7 @@ class Bf16Generator:
         if c1.k != 3 or c1.cin != 64 or c1.cout != 64 or model.upscale_times != 1 or model.c_init.cin != 3:
             raise NotImplementedError("bf16 inference is instantiated for kernel_size=3, filters=64, upscale_factor=2 "
                                       "(the topology of BASELINE.json's configs); use model.predict for other shapes")
-        if any(n1.norm != "batch" for (_, n1, _, _) in model.blocks):
-            raise NotImplementedError("bf16 inference folds BatchNormalization; instance-norm generators use model.predict")
+        self.instance = model.n_pre.norm == "instance"        # per-image statistics cannot be folded: bf16 norm kernels
         self.model = model
         self.rt = model.rt
         self._graphs = {}
@@ -56,6 +55,8 @@ class Bf16Generator:
 
     def _fold(self, conv, norm):
         ps = conv.ps
+        if self.instance:          # non-affine instance norm: only the convolution's bias is applied in its epilogue
+            return torch.ones(conv.cout, device=self.rt.device), ps[conv.name + "/bias"]
         scale = ps[norm.name + "/gamma"] / torch.sqrt(ps[norm.name + "/moving_variance"] + BN_EPS)
         shift = (ps[conv.name + "/bias"] - ps[norm.name + "/moving_mean"]) * scale + ps[norm.name + "/beta"]
         return scale.contiguous(), shift.contiguous()
@@ -93,16 +94,40 @@ class Bf16Generator:
             bf = lambda c, hh, ww: torch.empty(n, hh, ww, c, dtype=torch.bfloat16, device=dev)
             self._bufs[key] = {"skip": bf(64, h, w),
                                "a": bf(64, h, w), "b": bf(64, h, w), "c": bf(64, h, w), "u": bf(256, 2 * h, 2 * w),
+                               "z": bf(64, h, w) if self.instance else None,
+                               "stats": torch.empty(5, n * 64, dtype=torch.float32, device=dev) if self.instance else None,
                                "y": torch.empty(n, 3, 2 * h, 2 * w, dtype=torch.float32, device=dev)}
         return self._bufs[key]
 
     def _conv(self, x, w, y, scale, shift, act, alpha, res, n, h, wd):
         rt = self.rt
+        if self.instance:
+            return self._conv_instance_norm(x, w, y, shift, act, alpha, res, n, h, wd)
         d = L.ConvDesc(n, 64, h, wd, 64, h, wd, 3, 3, 1, 1, 1)
         ep = L.EpilogueBf16(scale.data_ptr(), shift.data_ptr(), act, 0.0, alpha.data_ptr() if alpha is not None else None,
                             res.data_ptr() if res is not None else None)
         L.check(rt.lib.vcg_conv2d_bf16_fwd(ctypes.byref(d), x.data_ptr(), w.data_ptr(), y.data_ptr(), ctypes.byref(ep), rt.stream),
                 "vcg_conv2d_bf16_fwd")
+
+    def _conv_instance_norm(self, x, w, y, bias, act, alpha, res, n, h, wd):
+        """conv (+bias) -> per-image statistics -> normalise + activation + Add, all on bf16 NHWC"""
+        rt = self.rt
+        z = self._buffers(n, h, wd)["z"]
+        d = L.ConvDesc(n, 64, h, wd, 64, h, wd, 3, 3, 1, 1, 1)
+        ep = L.EpilogueBf16(None, bias.data_ptr(), L.ACT_NONE, 0.0, None, None)
+        L.check(rt.lib.vcg_conv2d_bf16_fwd(ctypes.byref(d), x.data_ptr(), w.data_ptr(), z.data_ptr(), ctypes.byref(ep), rt.stream),
+                "vcg_conv2d_bf16_fwd")
+        st = self._buffers(n, h, wd)["stats"]
+        mean, var, scale, shift, invstd = (st[i] for i in range(5))
+        ws, wsn = rt.workspace(rt.lib.vcg_norm_stats_bf16_workspace_bytes(n, 64, h * wd, L.NORM_INSTANCE))
+        L.check(rt.lib.vcg_norm_stats_bf16(z.data_ptr(), n, 64, h * wd, L.NORM_INSTANCE, mean.data_ptr(), var.data_ptr(), ws, wsn,
+                                           rt.stream), "vcg_norm_stats_bf16")
+        L.check(rt.lib.vcg_norm_finalize(mean.data_ptr(), var.data_ptr(), None, None, 64, n, E.IN_EPS, scale.data_ptr(), shift.data_ptr(),
+                                         invstd.data_ptr(), None, None, 0.0, 0, rt.stream), "vcg_norm_finalize")
+        L.check(rt.lib.vcg_norm_act_fwd_bf16(z.data_ptr(), n, 64, h * wd, scale.data_ptr(), shift.data_ptr(), 1, act, 0.0,
+                                             alpha.data_ptr() if alpha is not None else None,
+                                             res.data_ptr() if res is not None else None, y.data_ptr(), rt.stream),
+                "vcg_norm_act_fwd_bf16")
 
     def forward(self, x):
         """x: device fp32 NCHW [n,3,h,w] in [-1,1] -> device fp32 NCHW [n,3,2h,2w] (buffer owned by the engine)"""

@@ -797,6 +797,33 @@ class GanTrainer:
             self._adam(G, self.g_slots)
         return content, adv
 
+    # -- checkpoint / resume (the reference only ever saves the generator: train_gan3.py:364-368) -----------
+    def save_state(self, path):
+        """everything a resumed run needs: G and D weights (reference layer names), both models' Adam moments and the
+        shared iteration counter, in one .safetensors archive"""
+        from safetensors.numpy import save_file
+        if self._t_dev is not None:
+            self.opt.iterations = int(self._t_dev[0].item())
+        out = {"G/" + k: v for k, v in self.G.get_weights_dict().items()}
+        out.update({"D/" + k: v for k, v in self.D.get_weights_dict().items()})
+        for tag, s in (("G", self.g_slots), ("D", self.d_slots)):
+            out["adam/%s/m" % tag] = s.m.cpu().numpy()
+            out["adam/%s/v" % tag] = s.v.cpu().numpy()
+        out["adam/iterations"] = np.asarray([self.opt.iterations], np.int64)
+        save_file(out, path, metadata={"format": "vcg-amd-trainer", "wiring": self.wiring})
+
+    def load_state(self, path):
+        from safetensors.numpy import load_file
+        d = load_file(path)
+        self.G.set_weights_dict({k[2:]: v for k, v in d.items() if k.startswith("G/")})
+        self.D.set_weights_dict({k[2:]: v for k, v in d.items() if k.startswith("D/")})
+        for tag, s in (("G", self.g_slots), ("D", self.d_slots)):
+            s.m.copy_(torch.from_numpy(d["adam/%s/m" % tag]))
+            s.v.copy_(torch.from_numpy(d["adam/%s/v" % tag]))
+        self.opt.iterations = int(d["adam/iterations"][0])
+        if self._t_dev is not None:
+            self._t_dev[0] = self.opt.iterations
+
     # -- loss read-back ---------------------------------------------------------------------------------
     def disc_loss_value(self, loss):
         if isinstance(loss, tuple):
