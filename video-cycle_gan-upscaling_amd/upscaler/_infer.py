@@ -168,7 +168,7 @@ class Bf16Generator:
         self.forward(xin)                  # warm-up: buffers exist, kernel attributes are set
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
             y = self.forward(xin)
         self._graphs[key] = (g, xin, y)
         return self._graphs[key]

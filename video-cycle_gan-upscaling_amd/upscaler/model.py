@@ -872,23 +872,24 @@ class GanTrainer:
         self.train_step(self._g_lr, self._g_hr)        # eager warm-up with the device-side counter (lazy buffers exist)
         torch.cuda.synchronize()
         it0 = self.opt.iterations
+        # capture_error_mode="thread_local": the RCCL watchdog thread may poll its events while this thread records
         if self.pg is None:
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                 fake = self.predict(self._g_lr)
                 ld = self.disc_step(self._g_hr, fake)
                 content, adv = self.gan_step(self._g_lr, self._g_hr)
             graphs = [graph]
         else:
             ga, gb, gc = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-            with torch.cuda.graph(ga):
+            with torch.cuda.graph(ga, capture_error_mode="thread_local"):
                 fake = self.predict(self._g_lr)
                 ld = self.disc_step(self._g_hr, fake, apply=False)
             pool = ga.pool()
-            with torch.cuda.graph(gb, pool=pool):
+            with torch.cuda.graph(gb, pool=pool, capture_error_mode="thread_local"):
                 self._apply_adam(self.D, self.d_slots)
                 content, adv = self.gan_step(self._g_lr, self._g_hr, apply=False)
-            with torch.cuda.graph(gc, pool=pool):
+            with torch.cuda.graph(gc, pool=pool, capture_error_mode="thread_local"):
                 self._apply_adam(self.G, self.g_slots)
             graphs = [ga, gb, gc]
         # capture only records: undo the host-side counter advance of the recording pass
