@@ -245,6 +245,12 @@ int vcg_norm_stats_bf16(const void* x, int n, int c, int hw, int mode, float* me
 int vcg_norm_act_fwd_bf16(const void* x, int n, int c, int hw, const float* scale, const float* shift, int per_sample, int act,
                           float alpha, const float* prelu_alpha, const void* residual, void* y, hipStream_t stream);
 
+/* weight (and bias) gradient of the bf16 3x3 stride-1 'same' 64->64 convolution: x, dy bf16 NHWC; dw fp32 in Keras' (3,3,in,out)
+ * layout (it accumulates into the fp32 master-weight gradient like vcg_conv2d_wgrad), dbias [64] fp32 or NULL. */
+size_t vcg_conv2d_bf16_wgrad_workspace_bytes(const vcg_conv_desc* d);
+int vcg_conv2d_bf16_wgrad(const vcg_conv_desc* d, const void* x, const void* dy, float* dw_hwio, float* dbias, void* ws, size_t ws_bytes,
+                          hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

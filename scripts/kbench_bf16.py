@@ -97,7 +97,29 @@ def bench_final(B):
              100 * nbytes / ms / 1e6 / PEAK_GBS, PEAK_GBS), flush=True)
 
 
+def bench_wgrad(B):
+    rt = E.Runtime.get()
+    dev = rt.device
+    h = w = 256
+    x = torch.randn(B, h, w, 64, device=dev).to(torch.bfloat16)
+    dy = torch.randn(B, h, w, 64, device=dev).to(torch.bfloat16)
+    dw = torch.empty(3, 3, 64, 64, device=dev)
+    db = torch.empty(64, device=dev)
+    d = L.ConvDesc(B, 64, h, w, 64, h, w, 3, 3, 1, 1, 1)
+    ws, wsn = rt.workspace(rt.lib.vcg_conv2d_bf16_wgrad_workspace_bytes(ctypes.byref(d)))
+    flop = 2.0 * 64 * 64 * 9 * h * w * B
+    nbytes = (x.numel() + dy.numel()) * 2
+    for name, dbp in (("trunk wgrad 3x3 64->64", None), ("trunk wgrad + dbias", db.data_ptr())):
+        def run():
+            L.check(rt.lib.vcg_conv2d_bf16_wgrad(ctypes.byref(d), x.data_ptr(), dy.data_ptr(), dw.data_ptr(), dbp, ws, wsn, rt.stream), "wgrad")
+        ms = timeit(run)
+        print("%-28s B=%d  %.3f ms  %7.1f TFLOP/s (%.1f%% of %.0f)  %6.0f GB/s algorithmic (%.1f%% of %.0f)"
+              % (name, B, ms, flop / ms / 1e9, 100 * flop / ms / 1e9 / PEAK_TF, PEAK_TF, nbytes / ms / 1e6,
+                 100 * nbytes / ms / 1e6 / PEAK_GBS, PEAK_GBS), flush=True)
+
+
 if __name__ == "__main__":
     main()
     bench_convt(int(sys.argv[1]) if len(sys.argv) > 1 else 32)
     bench_final(int(sys.argv[1]) if len(sys.argv) > 1 else 32)
+    bench_wgrad(int(sys.argv[1]) if len(sys.argv) > 1 else 32)

@@ -324,3 +324,28 @@ def test_bf16_generator_instance_norm(rt):
     e = rel_err(got, ref.numpy())
     report("bf16 generator (instance norm) predict res=%d n=%d %dx%d  err=%.2e" % (res, n, h, w, e))
     assert e < 3e-2
+
+
+@pytest.mark.parametrize("n,h,w", [(1, 8, 32), (2, 16, 64), (1, 13, 45), (3, 40, 72), (2, 5, 7)])
+def test_conv3x3_c64_bf16_wgrad(rt, n, h, w):
+    """weight / bias gradient of the bf16 trunk convolution (transposed LDS reads) against fp64 autograd on the same
+    bf16-rounded operands; the result is fp32, so only the accumulation order differs: 1e-4"""
+    from oracle import keras_ops as K
+    from upscaler import _lib as L
+    g = torch.Generator().manual_seed(n * 1000 + h * 10 + w)
+    x = torch.randn(n, 64, h, w, generator=g)
+    dy = torch.randn(n, 64, h, w, generator=g)
+    xb, dyb = _bf16_round(x), _bf16_round(dy)
+    wk = torch.zeros(3, 3, 64, 64, dtype=torch.float64, requires_grad=True)
+    b = torch.zeros(64, dtype=torch.float64, requires_grad=True)
+    (K.conv2d(xb, wk, b, 1, "same") * dyb).sum().backward()
+    xd, dyd = _to_nhwc_bf16(rt, x.to(rt.device)), _to_nhwc_bf16(rt, dy.to(rt.device))
+    dw = torch.empty(3, 3, 64, 64, dtype=torch.float32, device=rt.device)
+    db = torch.empty(64, dtype=torch.float32, device=rt.device)
+    d = L.ConvDesc(n, 64, h, w, 64, h, w, 3, 3, 1, 1, 1)
+    ws, wsn = rt.workspace(rt.lib.vcg_conv2d_bf16_wgrad_workspace_bytes(ctypes.byref(d)))
+    L.check(rt.lib.vcg_conv2d_bf16_wgrad(ctypes.byref(d), xd.data_ptr(), dyd.data_ptr(), dw.data_ptr(), db.data_ptr(), ws, wsn, rt.stream),
+            "vcg_conv2d_bf16_wgrad")
+    e_w, e_b = rel_err(dw, wk.grad), rel_err(db, b.grad)
+    report("bf16 wgrad 3x3 c64 n=%d %dx%d  dw err=%.2e  db err=%.2e" % (n, h, w, e_w, e_b))
+    assert e_w < 1e-4 and e_b < 1e-4

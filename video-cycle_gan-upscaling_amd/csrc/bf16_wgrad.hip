@@ -1,0 +1,270 @@
+// bf16-storage weight gradient of the 3x3 stride-1 'same' 64 -> 64 convolution (the generator trunk; gradient of
+// upscaling/upscaler/model.py:19,22,283 in the bf16 configs C3/C4 of BASELINE.json):
+//     dW[tap][ci][co] = sum over pixels of  dy[pixel][co] * x[pixel + tap][ci]          (fp32 result, Keras HWIO layout)
+// The contraction runs over PIXELS while the NHWC activations keep CHANNELS contiguous, i.e. both MFMA operands are
+// needed "transposed" (8 consecutive pixels of one channel per lane).  gfx950's ds_read_b64_tr_b16 delivers exactly
+// that from the natural [pixel][64 channels] LDS image (semantics measured with scripts/micro/tr_read_probe.hip: in a
+// 16-lane group, lane i receives halfword (i&3) of the 8 bytes addressed by lanes (i>>2)+4j, j = 0..3): a group fetches
+// 4 pixels x 16 channels and hands every lane 4 pixels of ITS channel; two reads make one operand fragment.  No
+// transposed staging pass, and the tap shift is plain address arithmetic on whole pixels (no alignment issue).
+//   * LDS image: 128-byte pixel rows whose two 64-byte halves are swapped when bit 1 of the pixel index is set: the four
+//     consecutive pixels of a transposed read then fall into four different 16-bank quarters (conflict-free);
+//   * persistent workgroups of 6 waves = 3 tap rows x 2 pixel halves of an 8x32-pixel tile; a wave keeps the whole
+//     [64 co] x [3 dx x 64 ci] block of its tap row in 192 accumulator VGPRs for the entire launch (12 MFMAs per
+//     2 + 6 operand fragments);
+//   * tiles stream HBM -> LDS by global_load_lds (double buffered, swizzle applied on the global side, out-of-image
+//     pixels fetched from a zero page);
+//   * per-wave partial blocks go to the workspace and are summed in a fixed order (deterministic) into Keras' layout.
+#include "vcg_common.hpp"
+#include <utility>
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+template <class F, int... Is>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Is...>) {
+    (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+__device__ __forceinline__ unsigned long long tr_read(unsigned addr) {
+    unsigned long long v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(addr));
+    return v;
+}
+
+constexpr int G_R = 8, G_C = 32;                       // output-pixel tile
+constexpr int G_DYB = G_R * G_C * 128;                 // 32768
+constexpr int G_XP = G_C + 2;                          // halo tile pitch (pixels)
+constexpr int G_XB = (G_R + 2) * G_XP * 128;           // 43520
+constexpr int G_NW = 6;
+constexpr int G_CHUNKS = (G_DYB + G_XB) / 16;          // 4768 16-byte chunks per stage
+constexpr int G_NDMA = (G_CHUNKS + G_NW * 64 - 1) / (G_NW * 64);      // 13 DMA instructions per lane and stage
+constexpr int G_BUF = G_NDMA * G_NW * 64 * 16;         // one stage, padded to whole DMA instructions (79872 B): the lanes
+                                                       // past the last chunk land in the padding
+constexpr int G_WAVE_FLOATS = 12 * 16 * 64;            // a wave's partial block: 12 tiles x 16 registers x 64 lanes
+
+struct WgParams {
+    const unsigned char* x;      // bf16 NHWC [n][h][w][64]
+    const unsigned char* dy;     // bf16 NHWC [n][h][w][64]
+    float* ws;                   // [grid][6][G_WAVE_FLOATS]
+    int n, h, w_, tiles_x, tiles_y, total;
+};
+
+__global__ __launch_bounds__(G_NW * 64, 1) void wgrad3x3_c64_bf16_kernel(WgParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int dyi = wv >> 1, ph = wv & 1;
+    const unsigned lds0 = (unsigned)(size_t)smem;
+
+    // lane constants of the transposed reads: pixel 8h + q (+dx), first channel 16*((l>>4)&1) + 4*(l&3) of the 32-block
+    const int h8 = (lane >> 5) * 8, q = (lane & 15) >> 2;
+    const int chb = (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;             // byte offset inside a 64-byte half
+    unsigned abase[2];                                                           // dy: [co half]
+#pragma unroll
+    for (int coh = 0; coh < 2; ++coh)
+        abase[coh] = (unsigned)((h8 + q) * 128 + ((64 * coh + chb) ^ (64 * ((q >> 1) & 1))));
+    unsigned bbase[3][2][2];                                                     // x: [dx][ci half][row parity of the k-step]
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+        for (int cih = 0; cih < 2; ++cih)
+#pragma unroll
+            for (int ip = 0; ip < 2; ++ip) {
+                const int sb = ((ip + dyi) & 1) ^ (((q + dx) >> 1) & 1);
+                bbase[dx][cih][ip] = (unsigned)(G_DYB + (dyi * G_XP + h8 + q + dx) * 128 + ((64 * cih + chb) ^ (64 * sb)));
+            }
+
+    f32x16 acc[3][2][2];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[a][b][c][e] = 0.f;
+
+    auto dma = [&](int tile, int buf) {
+        const int txi = tile % p.tiles_x, t2 = tile / p.tiles_x, tyi = t2 % p.tiles_y, img = t2 / p.tiles_y;
+        const int y0 = tyi * G_R, x0 = txi * G_C;
+#pragma unroll
+        for (int k = 0; k < G_NDMA; ++k) {
+            const int s = min(k * (G_NW * 64) + tid, G_CHUNKS - 1);          // the tail re-fetches the last chunk into its own slot
+            const bool isx = s >= G_DYB / 16;
+            const int sl = isx ? s - G_DYB / 16 : s;
+            const int P = sl >> 3, cs = (sl & 7) ^ (4 * ((P >> 1) & 1));     // stored chunk (sl&7) holds source chunk cs
+            const int row = isx ? P / G_XP : P >> 5, col = isx ? P - row * G_XP : P & 31;
+            const int gy = y0 + row - (isx ? 1 : 0), gx = x0 + col - (isx ? 1 : 0);
+            const bool ok = (unsigned)gy < (unsigned)p.h && (unsigned)gx < (unsigned)p.w_;
+            const unsigned char* base = isx ? p.x : p.dy;
+            const unsigned char* src = ok ? base + ((long)(img * p.h + gy) * p.w_ + gx) * 128 + cs * 16 : (const unsigned char*)vcg_zero_word;
+            // lanes of one instruction must write consecutive 16-byte slots: slot index = k*384 + tid
+            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src,
+                                             (void __attribute__((address_space(3)))*)(smem + buf * G_BUF + (k * (G_NW * 64) + wv * 64) * 16), 16, 0, 0);
+        }
+    };
+
+    int tile = blockIdx.x, buf = 0;
+    if (tile < p.total) dma(tile, 0);
+    for (; tile < p.total; tile += gridDim.x, buf ^= 1) {
+        __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0): this wave's part of the stage has landed
+        lds_barrier();                               // ... and everyone else's; the other buffer is free again
+        const int next = tile + gridDim.x;
+        if (next < p.total) dma(next, buf ^ 1);
+        const unsigned lb = lds0 + buf * G_BUF;
+
+        // 8 k-steps of 16 pixels: rows ph*4 .. ph*4+3, column halves 0/1
+        static_for<8>([&](auto ic) {
+            constexpr int ks = decltype(ic)::value, i = ks >> 1, cb = ks & 1;
+            const int row = ph * 4 + i;
+            unsigned long long fa[2][2], fb[3][2][2];
+#pragma unroll
+            for (int coh = 0; coh < 2; ++coh)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) fa[coh][t] = tr_read(lb + abase[coh] + (unsigned)((row * G_C + cb * 16 + 4 * t) * 128));
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+                for (int cih = 0; cih < 2; ++cih)
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+                        fb[dx][cih][t] = tr_read(lb + bbase[dx][cih][i & 1] + (unsigned)((row * G_XP + cb * 16 + 4 * t) * 128));
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[1][0]), "+v"(fa[1][1]), "+v"(fb[0][0][0]), "+v"(fb[0][0][1]),
+                           "+v"(fb[0][1][0]), "+v"(fb[0][1][1]), "+v"(fb[1][0][0]), "+v"(fb[1][0][1]), "+v"(fb[1][1][0]), "+v"(fb[1][1][1]),
+                           "+v"(fb[2][0][0]), "+v"(fb[2][0][1]), "+v"(fb[2][1][0]), "+v"(fb[2][1][1]));
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+                for (int cih = 0; cih < 2; ++cih) {
+                    typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+                    const u64x2 bv = {fb[dx][cih][0], fb[dx][cih][1]};
+                    const bf16x8 b = __builtin_bit_cast(bf16x8, bv);
+#pragma unroll
+                    for (int coh = 0; coh < 2; ++coh) {
+                        const u64x2 av = {fa[coh][0], fa[coh][1]};
+                        acc[dx][cih][coh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), b, acc[dx][cih][coh], 0, 0, 0);
+                    }
+                }
+        });
+    }
+
+    // this wave's partial block: raw register dump (coalesced), decoded by the reduction
+    float* out = p.ws + ((long)blockIdx.x * G_NW + wv) * G_WAVE_FLOATS;
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+        for (int cih = 0; cih < 2; ++cih)
+#pragma unroll
+            for (int coh = 0; coh < 2; ++coh)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) out[(((dx * 2 + cih) * 2 + coh) * 16 + e) * 64 + lane] = acc[dx][cih][coh][e];
+}
+
+// dW[tap = dyi*3+dx][ci][co] = sum over workgroups and the two pixel-half waves of tap row dyi, in a fixed order
+__global__ void wgrad3x3_c64_reduce_kernel(const float* __restrict__ ws, int nblocks, float* __restrict__ dw) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;             // output element, Keras (3,3,64 ci,64 co) order
+    if (idx >= 9 * 64 * 64) return;
+    const int co = idx & 63, ci = (idx >> 6) & 63, tap = idx >> 12, dyi = tap / 3, dx = tap - 3 * dyi;
+    const int coh = co >> 5, cr = co & 31, cih = ci >> 5;
+    // D[row = co in block][col = ci in block]: register e, lane l with row = (e&3) + 8*(e>>2) + 4*(l>>5), col = l&31
+    const int hsel = (cr >> 2) & 1, e = (cr & 3) + 4 * (cr >> 3), l = (ci & 31) + 32 * hsel;
+    const long off = ((((long)dx * 2 + cih) * 2 + coh) * 16 + e) * 64 + l;
+    float s = 0.f;
+    for (int b = 0; b < nblocks; ++b)
+        for (int ph = 0; ph < 2; ++ph) s += ws[((long)b * G_NW + dyi * 2 + ph) * G_WAVE_FLOATS + off];
+    dw[idx] = s;
+}
+
+__global__ __launch_bounds__(256) void bias_grad_bf16_kernel(const bf16x8* __restrict__ dy, long pixels, float* __restrict__ part) {
+    // 64 channels: thread = (pixel lane 0..31, 8-channel chunk 0..7); per-block partial sums, reduced by the caller's second pass
+    __shared__ float red[256 * 8];
+    const int ch = threadIdx.x & 7, pl = threadIdx.x >> 3;
+    float s[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s[j] = 0.f;
+    for (long px = (long)blockIdx.x * 32 + pl; px < pixels; px += (long)gridDim.x * 32) {
+        const bf16x8 v = dy[px * 8 + ch];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s[j] += (float)v[j];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[threadIdx.x * 8 + j] = s[j];
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        float t = 0.f;
+        for (int l = 0; l < 32; ++l) t += red[(l * 8 + (threadIdx.x >> 3)) * 8 + (threadIdx.x & 7)];
+        part[(long)blockIdx.x * 64 + threadIdx.x] = t;
+    }
+}
+
+__global__ void bias_grad_final_kernel(const float* __restrict__ part, int nblocks, float* __restrict__ db) {
+    const int c = threadIdx.x;
+    if (c >= 64) return;
+    double s = 0.0;
+    for (int b = 0; b < nblocks; ++b) s += part[(long)b * 64 + c];
+    db[c] = (float)s;
+}
+
+constexpr int G_GRID = 256;
+constexpr int G_BIAS_BLOCKS = 512;
+
+}  // namespace
+
+extern "C" {
+
+size_t vcg_conv2d_bf16_wgrad_workspace_bytes(const vcg_conv_desc* d) {
+    if (!d) return 0;
+    return (size_t)G_GRID * G_NW * G_WAVE_FLOATS * sizeof(float) + (size_t)G_BIAS_BLOCKS * 64 * sizeof(float);
+}
+
+int vcg_conv2d_bf16_wgrad(const vcg_conv_desc* d, const void* x, const void* dy, float* dw_hwio, float* dbias, void* ws, size_t ws_bytes,
+                          hipStream_t stream) {
+    VCG_CHECK_PTR(d); VCG_CHECK_PTR(x); VCG_CHECK_PTR(dy); VCG_CHECK_PTR(dw_hwio); VCG_CHECK_PTR(ws);
+    if (d->n <= 0 || d->h <= 0 || d->w <= 0 || d->oh != d->h || d->ow != d->w) return VCG_E_SHAPE;
+    if (d->cin != 64 || d->cout != 64 || d->kh != 3 || d->kw != 3 || d->stride != 1 || d->pad_top != 1 || d->pad_left != 1) return VCG_E_UNSUPPORTED;
+    if (ws_bytes < vcg_conv2d_bf16_wgrad_workspace_bytes(d)) return VCG_E_WORKSPACE;
+    WgParams p;
+    p.x = (const unsigned char*)x;
+    p.dy = (const unsigned char*)dy;
+    p.ws = (float*)ws;
+    p.n = d->n; p.h = d->h; p.w_ = d->w;
+    p.tiles_x = ceil_div(d->w, G_C);
+    p.tiles_y = ceil_div(d->h, G_R);
+    p.total = p.n * p.tiles_x * p.tiles_y;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)wgrad3x3_c64_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * G_BUF);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    const int grid = p.total < G_GRID ? p.total : G_GRID;
+    wgrad3x3_c64_bf16_kernel<<<grid, G_NW * 64, 2 * G_BUF, stream>>>(p);
+    VCG_LAUNCH_CHECK();
+    wgrad3x3_c64_reduce_kernel<<<(9 * 64 * 64 + 255) / 256, 256, 0, stream>>>((const float*)ws, grid, dw_hwio);
+    VCG_LAUNCH_CHECK();
+    if (dbias) {
+        float* part = (float*)ws + (size_t)G_GRID * G_NW * G_WAVE_FLOATS;
+        const long pixels = (long)d->n * d->h * d->w;
+        const int nb = (int)(pixels / 32 < G_BIAS_BLOCKS ? (pixels + 31) / 32 : G_BIAS_BLOCKS);
+        bias_grad_bf16_kernel<<<nb, 256, 0, stream>>>((const bf16x8*)dy, pixels, part);
+        VCG_LAUNCH_CHECK();
+        bias_grad_final_kernel<<<1, 64, 0, stream>>>(part, nb, dbias);
+        VCG_LAUNCH_CHECK();
+    }
+    return VCG_OK;
+}
+
+}  // extern "C"
