@@ -244,6 +244,12 @@ int vcg_norm_stats_bf16(const void* x, int n, int c, int hw, int mode, float* me
                         hipStream_t stream);
 int vcg_norm_act_fwd_bf16(const void* x, int n, int c, int hw, const float* scale, const float* shift, int per_sample, int act,
                           float alpha, const float* prelu_alpha, const void* residual, void* y, hipStream_t stream);
+/* backward, same contract as vcg_norm_act_bwd (x = the layer's INPUT, statistics as saved by the forward pass; dx bf16 NHWC;
+ * dgamma / dbeta / dprelu_alpha fp32 [c] or NULL) */
+size_t vcg_norm_act_bwd_bf16_workspace_bytes(int n, int c, int hw, int mode);
+int vcg_norm_act_bwd_bf16(const void* x, const void* dy, int n, int c, int hw, int mode, const float* mean, const float* invstd,
+                          const float* gamma, const float* beta, int act, float act_alpha, const float* prelu_alpha, int use_batch_stats,
+                          void* dx, float* dgamma, float* dbeta, float* dprelu_alpha, void* ws, size_t ws_bytes, hipStream_t stream);
 
 /* weight (and bias) gradient of the bf16 3x3 stride-1 'same' 64->64 convolution: x, dy bf16 NHWC; dw fp32 in Keras' (3,3,in,out)
  * layout (it accumulates into the fp32 master-weight gradient like vcg_conv2d_wgrad), dbias [64] fp32 or NULL. */

@@ -349,3 +349,58 @@ def test_conv3x3_c64_bf16_wgrad(rt, n, h, w):
     e_w, e_b = rel_err(dw, wk.grad), rel_err(db, b.grad)
     report("bf16 wgrad 3x3 c64 n=%d %dx%d  dw err=%.2e  db err=%.2e" % (n, h, w, e_w, e_b))
     assert e_w < 1e-4 and e_b < 1e-4
+
+
+@pytest.mark.parametrize("mode,n,c,h,w,act", [("batch", 4, 64, 24, 20, "prelu"), ("instance", 2, 64, 30, 33, "none"),
+                                              ("batch", 2, 128, 9, 11, "lrelu"), ("instance", 3, 64, 16, 16, "prelu")])
+def test_norm_bwd_bf16(rt, mode, n, c, h, w, act):
+    """bf16 NHWC norm + activation backward against fp64 autograd on the same bf16 values: dx (bf16 output, 2^-8), and
+    the fp32 parameter gradients dgamma / dbeta / dalpha (1e-4)"""
+    from upscaler import _engine as E, _lib as L
+    g = torch.Generator().manual_seed(c + h + n)
+    x = torch.randn(n, c, h, w, generator=g) * 1.5 + torch.randn(1, c, 1, 1, generator=g)
+    dy = torch.randn(n, c, h, w, generator=g)
+    gamma, beta = torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g) * 0.3
+    alpha = torch.rand(c, generator=g) * 0.4 + 0.05
+    inst = mode == "instance"
+    eps = E.IN_EPS if inst else E.BN_EPS
+    xb, dyb = _bf16_round(x).requires_grad_(True), _bf16_round(dy)
+    gr, br, ar = (t.double().clone().requires_grad_(True) for t in (gamma, beta, alpha))
+    dims = (2, 3) if inst else (0, 2, 3)
+    mu, var = xb.mean(dims, keepdim=True), xb.var(dims, unbiased=False, keepdim=True)
+    xh = (xb - mu) / torch.sqrt(var + eps)
+    u = xh if inst else xh * gr.view(1, c, 1, 1) + br.view(1, c, 1, 1)
+    if act == "prelu":
+        y = torch.clamp(u, min=0) + ar.view(1, c, 1, 1) * torch.clamp(u, max=0)
+    elif act == "lrelu":
+        y = torch.where(u > 0, u, 0.2 * u)
+    else:
+        y = u
+    (y * dyb).sum().backward()
+
+    xd, dyd = _to_nhwc_bf16(rt, x.to(rt.device)), _to_nhwc_bf16(rt, dy.to(rt.device))
+    rows = n if inst else 1
+    code = L.NORM_INSTANCE if inst else L.NORM_BATCH
+    mean, varr, scale, shift, invstd = (torch.empty(rows * c, device=rt.device) for _ in range(5))
+    ws, wsn = rt.workspace(rt.lib.vcg_norm_stats_bf16_workspace_bytes(n, c, h * w, code))
+    L.check(rt.lib.vcg_norm_stats_bf16(xd.data_ptr(), n, c, h * w, code, mean.data_ptr(), varr.data_ptr(), ws, wsn, rt.stream), "stats")
+    gd, bd, ad = gamma.to(rt.device), beta.to(rt.device), alpha.to(rt.device)
+    L.check(rt.lib.vcg_norm_finalize(mean.data_ptr(), varr.data_ptr(), None if inst else gd.data_ptr(), None if inst else bd.data_ptr(), c, rows,
+                                     eps, scale.data_ptr(), shift.data_ptr(), invstd.data_ptr(), None, None, 0.0, 0, rt.stream), "finalize")
+    dx = torch.empty_like(xd)
+    dga, dbe, dal = (torch.zeros(c, device=rt.device) for _ in range(3))
+    ws, wsn = rt.workspace(rt.lib.vcg_norm_act_bwd_bf16_workspace_bytes(n, c, h * w, code))
+    L.check(rt.lib.vcg_norm_act_bwd_bf16(xd.data_ptr(), dyd.data_ptr(), n, c, h * w, code, mean.data_ptr(), invstd.data_ptr(),
+                                         None if inst else gd.data_ptr(), None if inst else bd.data_ptr(),
+                                         {"none": L.ACT_NONE, "prelu": L.ACT_PRELU, "lrelu": L.ACT_LRELU}[act], 0.2,
+                                         ad.data_ptr() if act == "prelu" else None, 1, dx.data_ptr(), None if inst else dga.data_ptr(),
+                                         None if inst else dbe.data_ptr(), dal.data_ptr() if act == "prelu" else None, ws, wsn, rt.stream), "norm_bwd")
+    e_dx = rel_err(_to_nchw_f32(rt, dx), xb.grad)
+    errs = {"dx": e_dx}
+    if not inst:
+        errs["dgamma"], errs["dbeta"] = rel_err(dga, gr.grad), rel_err(dbe, br.grad)
+    if act == "prelu":
+        errs["dalpha"] = rel_err(dal, ar.grad)
+    report("bf16 norm bwd %s n=%d c=%d %dx%d act=%s  %s" % (mode, n, c, h, w, act, "  ".join("%s=%.2e" % kv for kv in errs.items())))
+    assert e_dx < TOL_BF16
+    assert all(v < 2e-4 for k, v in errs.items() if k != "dx")

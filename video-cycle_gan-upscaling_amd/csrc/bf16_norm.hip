@@ -99,6 +99,124 @@ __global__ __launch_bounds__(256) void norm_act_fwd_bf16_kernel(const bf16x8* __
     y[i] = o;
 }
 
+
+// ---- backward -------------------------------------------------------------------------------------------------
+// y = act(u), u = gamma*xhat + beta, xhat = (x - mean)*invstd.   pass 1: per channel (per image in instance mode)
+// sum dz, sum dz*xhat, sum dy*min(u,0) over a slab of pixels -> partials;  pass 2: the partials are summed in a fixed
+// order by every block that needs them (tiny: <= 128 slabs) and dx = gamma*invstd*(dz - S1/M - xhat*S2/M) is applied.
+__device__ __forceinline__ float act_grad_bf16(float u, int act, float slope) {
+    if (act == VCG_ACT_PRELU || act == VCG_ACT_LRELU) return u > 0.f ? 1.f : slope;
+    return 1.f;
+}
+
+__global__ __launch_bounds__(256) void norm_bwd_partial_bf16_kernel(const bf16x8* __restrict__ x, const bf16x8* __restrict__ dy, int c8,
+                                                                     long group_pixels, int slabs_per_group, int per_sample,
+                                                                     const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                     int act, float alpha, const float* __restrict__ prelu,
+                                                                     float* __restrict__ part) {
+    extern __shared__ float red[];                                   // [3][256*8]
+    const int grp = blockIdx.x / slabs_per_group, slab = blockIdx.x - grp * slabs_per_group;
+    const int ch = threadIdx.x % c8, pl = threadIdx.x / c8, npl = 256 / c8;
+    const long gbase = (long)grp * group_pixels * c8;
+    const int sidx = (per_sample ? grp * c8 * 8 : 0) + ch * 8;
+    float mu[8], is[8], ga[8], be[8], sl[8], s1[8], s2[8], s3[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        mu[j] = mean[sidx + j];
+        is[j] = invstd[sidx + j];
+        ga[j] = gamma ? gamma[ch * 8 + j] : 1.f;
+        be[j] = beta ? beta[ch * 8 + j] : 0.f;
+        sl[j] = act == VCG_ACT_PRELU ? prelu[ch * 8 + j] : alpha;
+        s1[j] = s2[j] = s3[j] = 0.f;
+    }
+    const long p0 = (long)slab * SPB, p1 = p0 + SPB < group_pixels ? p0 + SPB : group_pixels;
+    if (pl < npl)
+        for (long p = p0 + pl; p < p1; p += npl) {
+            const bf16x8 xv = x[gbase + p * c8 + ch], dv = dy[gbase + p * c8 + ch];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float xh = ((float)xv[j] - mu[j]) * is[j], u = xh * ga[j] + be[j], d = (float)dv[j];
+                const float dz = d * act_grad_bf16(u, act, sl[j]);
+                s1[j] += dz;
+                s2[j] += dz * xh;
+                s3[j] += d * fminf(u, 0.f);
+            }
+        }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        red[threadIdx.x * 8 + j] = s1[j];
+        red[2048 + threadIdx.x * 8 + j] = s2[j];
+        red[4096 + threadIdx.x * 8 + j] = s3[j];
+    }
+    __syncthreads();
+    if (threadIdx.x < c8 * 8) {
+        const int cc = threadIdx.x;
+        float t1 = 0.f, t2 = 0.f, t3 = 0.f;
+        for (int l = 0; l < npl; ++l) {
+            const int o = (l * c8 + (cc >> 3)) * 8 + (cc & 7);
+            t1 += red[o];
+            t2 += red[2048 + o];
+            t3 += red[4096 + o];
+        }
+        float* pp = part + ((long)blockIdx.x * c8 * 8 + cc) * 3;
+        pp[0] = t1;
+        pp[1] = t2;
+        pp[2] = t3;
+    }
+}
+
+// group sums [groups*c][3] (and the parameter gradients, summed over the images in instance mode)
+__global__ void norm_bwd_sums_bf16_kernel(const float* __restrict__ part, int c, int slabs_per_group, int groups, float* __restrict__ sums,
+                                          float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ dalpha) {
+    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch >= c) return;
+    double g1 = 0.0, g2 = 0.0, g3 = 0.0;
+    for (int grp = 0; grp < groups; ++grp) {
+        double s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        for (int b = 0; b < slabs_per_group; ++b) {
+            const float* pp = part + (((long)grp * slabs_per_group + b) * c + ch) * 3;
+            s1 += pp[0];
+            s2 += pp[1];
+            s3 += pp[2];
+        }
+        sums[((long)grp * c + ch) * 2] = (float)s1;
+        sums[((long)grp * c + ch) * 2 + 1] = (float)s2;
+        g1 += s1;
+        g2 += s2;
+        g3 += s3;
+    }
+    if (dbeta) dbeta[ch] = (float)g1;
+    if (dgamma) dgamma[ch] = (float)g2;
+    if (dalpha) dalpha[ch] = (float)g3;
+}
+
+__global__ __launch_bounds__(256) void norm_bwd_apply_bf16_kernel(const bf16x8* __restrict__ x, const bf16x8* __restrict__ dy, long total8, int c8,
+                                                                   long pix_per_img, long group_pixels, int per_sample,
+                                                                   const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                                   const float* __restrict__ gamma, const float* __restrict__ beta, int act,
+                                                                   float alpha, const float* __restrict__ prelu, const float* __restrict__ sums,
+                                                                   int use_batch_stats, bf16x8* __restrict__ dx) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total8) return;
+    const int ch = (int)(i % c8) * 8;
+    const long img = per_sample ? i / (pix_per_img * c8) : 0;
+    const long sidx = img * c8 * 8 + ch;
+    const float inv_m = 1.f / (float)group_pixels;
+    const bf16x8 xv = x[i], dv = dy[i];
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float is = invstd[sidx + j], ga = gamma ? gamma[ch + j] : 1.f, be = beta ? beta[ch + j] : 0.f;
+        const float xh = ((float)xv[j] - mean[sidx + j]) * is, u = xh * ga + be;
+        const float sl = act == VCG_ACT_PRELU ? prelu[ch + j] : alpha;
+        float dz = (float)dv[j] * act_grad_bf16(u, act, sl);
+        if (use_batch_stats) dz = dz - sums[(sidx + j) * 2] * inv_m - xh * sums[(sidx + j) * 2 + 1] * inv_m;
+        o[j] = (__bf16)(ga * is * dz);
+    }
+    dx[i] = o;
+}
+
 }  // namespace
 
 extern "C" {
@@ -136,6 +254,39 @@ int vcg_norm_act_fwd_bf16(const void* x, int n, int c, int hw, const float* scal
     norm_act_fwd_bf16_kernel<<<(unsigned)((total8 + 255) / 256), 256, 0, stream>>>((const bf16x8*)x, total8, c / 8, hw, scale, shift,
                                                                                   per_sample, act, alpha, prelu_alpha, (const bf16x8*)residual,
                                                                                   (bf16x8*)y);
+    VCG_LAUNCH_CHECK();
+    return VCG_OK;
+}
+
+size_t vcg_norm_act_bwd_bf16_workspace_bytes(int n, int c, int hw, int mode) {
+    const long gp = mode == VCG_NORM_INSTANCE ? hw : (long)n * hw;
+    const long groups = mode == VCG_NORM_INSTANCE ? n : 1;
+    return (size_t)(groups * ((gp + SPB - 1) / SPB) * c * 3 + groups * c * 2) * sizeof(float);
+}
+
+int vcg_norm_act_bwd_bf16(const void* x, const void* dy, int n, int c, int hw, int mode, const float* mean, const float* invstd,
+                          const float* gamma, const float* beta, int act, float act_alpha, const float* prelu_alpha, int use_batch_stats,
+                          void* dx, float* dgamma, float* dbeta, float* dprelu_alpha, void* ws, size_t ws_bytes, hipStream_t stream) {
+    VCG_CHECK_PTR(x); VCG_CHECK_PTR(dy); VCG_CHECK_PTR(mean); VCG_CHECK_PTR(invstd); VCG_CHECK_PTR(dx); VCG_CHECK_PTR(ws);
+    if (n <= 0 || c <= 0 || hw <= 0) return VCG_E_SHAPE;
+    if (c % 8 != 0 || c > 256 || act == VCG_ACT_TANH) return VCG_E_UNSUPPORTED;
+    if (act == VCG_ACT_PRELU && !prelu_alpha) return VCG_E_NULL;
+    if (ws_bytes < vcg_norm_act_bwd_bf16_workspace_bytes(n, c, hw, mode)) return VCG_E_WORKSPACE;
+    const int inst = mode == VCG_NORM_INSTANCE;
+    const long gp = inst ? hw : (long)n * hw;
+    const int groups = inst ? n : 1;
+    const int slabs = (int)((gp + SPB - 1) / SPB);
+    float* part = (float*)ws;
+    float* sums = part + (size_t)groups * slabs * c * 3;
+    norm_bwd_partial_bf16_kernel<<<groups * slabs, 256, 3 * 2048 * sizeof(float), stream>>>((const bf16x8*)x, (const bf16x8*)dy, c / 8, gp, slabs, inst,
+                                                                                             mean, invstd, gamma, beta, act, act_alpha, prelu_alpha, part);
+    VCG_LAUNCH_CHECK();
+    norm_bwd_sums_bf16_kernel<<<ceil_div(c, 64), 64, 0, stream>>>(part, c, slabs, groups, sums, dgamma, dbeta, dprelu_alpha);
+    VCG_LAUNCH_CHECK();
+    const long total8 = (long)n * hw * (c / 8);
+    norm_bwd_apply_bf16_kernel<<<(unsigned)((total8 + 255) / 256), 256, 0, stream>>>((const bf16x8*)x, (const bf16x8*)dy, total8, c / 8, hw, gp, inst, mean,
+                                                                                    invstd, gamma, beta, act, act_alpha, prelu_alpha, sums,
+                                                                                    use_batch_stats, (bf16x8*)dx);
     VCG_LAUNCH_CHECK();
     return VCG_OK;
 }

@@ -88,6 +88,9 @@ SIGNATURES = {
     "vcg_norm_stats_bf16_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "vcg_norm_stats_bf16": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P, c_size_t, _P]),
     "vcg_norm_act_fwd_bf16": (c_int, [_P, c_int, c_int, c_int, _P, _P, c_int, c_int, c_float, _P, _P, _P, _P]),
+    "vcg_norm_act_bwd_bf16_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "vcg_norm_act_bwd_bf16": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_int, c_float, _P, c_int, _P, _P, _P, _P, _P,
+                                      c_size_t, _P]),
     "vcg_conv2d_bf16_wgrad_workspace_bytes": (c_size_t, [_D]),
     "vcg_conv2d_bf16_wgrad": (c_int, [_D, _P, _P, _P, _P, _P, c_size_t, _P]),
     "vcg_pack_first9x9_bf16": (c_int, [_P, _P, _P]),
