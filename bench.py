@@ -100,6 +100,8 @@ def main():
     ap.add_argument("--content", default="mse", choices=["mse", "vgg_mse"],
                     help="content loss: pixel MSE (C2 as SURVEY 8d defines it) or the reference's default VGG_MSE_LOSS form with "
                          "seeded random VGG19 weights (ImageNet weights cannot be fetched offline)")
+    ap.add_argument("--trunk-dtype", default="fp32", choices=["fp32", "bf16"],
+                    help="bf16: the generator's residual trunk trains on bf16 activations (mixed precision; NOT config C2, reported as such)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying one hipGraph per step")
     ap.add_argument("--cpu-sample-batch", type=int, default=2)
@@ -122,7 +124,8 @@ def main():
     group = _dist.init_from_env("nccl") if world > 1 else None
 
     h = args.lr_size
-    G = PM.make_upscaler_orig((2 * h, 2 * h, 3), kernel_size=3, upscale_factor=2, res_block_num=args.res_blocks, seed=7)
+    G = PM.make_upscaler_orig((2 * h, 2 * h, 3), kernel_size=3, upscale_factor=2, res_block_num=args.res_blocks, seed=7,
+                              trunk_dtype=args.trunk_dtype)
     D = (PM.make_discriminator_patchgan_70((2 * h, 2 * h, 3), seed=11) if args.disc == "patchgan"
          else PM.make_discriminator_simple_512((2 * h, 2 * h, 3), seed=11))
     if group is not None:                     # identical replicas: broadcast rank 0's weights
@@ -213,7 +216,8 @@ def main():
         out = {
             "metric": METRIC, "value": round(frames / dt, 3), "unit": "frames/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if args.trunk_dtype == "fp32" else "bf16 trunk activations / f32 elsewhere (mixed; not C2)", "data": "synthetic",
             "config": {"workload": "C2: make_upscaler_orig((%d,%d,3),k=3,x2,res=%d) + %s, batch %d/GPU, "
                                    "gan2 wiring, Wasserstein + %s, faithful 3-call step incl. predict pass"
                                    % (2 * h, 2 * h, args.res_blocks, "PatchGAN-70" if args.disc == "patchgan" else "simple_512",
@@ -223,7 +227,7 @@ def main():
             "last_losses": [round(float(v), 6) for v in losses],
             "roofline": roof,
         }
-        if world == 1 and not args.no_cpu_baseline and args.content == "mse":
+        if world == 1 and not args.no_cpu_baseline and args.content == "mse" and args.trunk_dtype == "fp32":
             out["cpu_baseline"] = cpu_baseline(args.res_blocks, args.cpu_sample_batch, h)
         print(json.dumps(out), flush=True)
     if group is not None:

@@ -175,3 +175,48 @@ def glorot_uniform(rng, shape, fan_in, fan_out):
     import numpy as np
     limit = math.sqrt(6.0 / (fan_in + fan_out))
     return rng.uniform(-limit, limit, size=shape).astype(np.float32)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# bf16 storage emulation (BASELINE.json configs C3-C5): the product keeps the trunk's activations and their gradients
+# in bf16 while all arithmetic is fp32.  These ops mark the storage points in the restatement so that parity of the bf16
+# path can be asserted tightly (same roundings at the same places) instead of through loose "bf16-sized" bounds.
+# ---------------------------------------------------------------------------------------------------------------
+def _r(x):
+    return x.to(torch.bfloat16).to(x.dtype)
+
+
+class _Bf16Store(torch.autograd.Function):
+    """tensor stored in bf16: value rounded forward, its gradient rounded backward"""
+    @staticmethod
+    def forward(ctx, x):
+        return _r(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _r(g)
+
+
+class _Bf16RoundFwd(torch.autograd.Function):
+    """value rounded to bf16, gradient passed through (bf16 copy of an fp32 master tensor)"""
+    @staticmethod
+    def forward(ctx, x):
+        return _r(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+class _Bf16RoundGrad(torch.autograd.Function):
+    """identity forward, gradient rounded to bf16 backward"""
+    @staticmethod
+    def forward(ctx, x):
+        return x.clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        return _r(g)
+
+
+bf16_store, bf16_round_fwd, bf16_round_grad = _Bf16Store.apply, _Bf16RoundFwd.apply, _Bf16RoundGrad.apply

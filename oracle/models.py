@@ -98,11 +98,18 @@ def init_upscaler_orig(output_image_shape, kernel_size=5, filters=64, upscale_fa
     return w
 
 
-def upscaler_orig_forward(w, x_nhwc, training, res_block_num, upscale_factor, taps=None, norm="batch"):
+def upscaler_orig_forward(w, x_nhwc, training, res_block_num, upscale_factor, taps=None, norm="batch", trunk_bf16=False):
     """x_nhwc: [N,h,w,3] -> ([N,h*f,w*f,3], bn_updates).  ``training`` selects batch vs moving BN
     statistics (Keras learning phase: predict=0, train_on_batch=1).  ``taps`` (optional dict)
-    receives named NCHW intermediates for kernel-level parity tests."""
+    receives named NCHW intermediates for kernel-level parity tests.  ``trunk_bf16`` marks the tensors the
+    product's ``trunk_dtype='bf16'`` mode stores in bf16 (values and gradients; keras_ops.bf16_*)."""
     upd = OrderedDict()
+    st = K.bf16_store if trunk_bf16 else (lambda v: v)
+    rf = K.bf16_round_fwd if trunk_bf16 else (lambda v: v)
+    rg = K.bf16_round_grad if trunk_bf16 else (lambda v: v)
+
+    def tconv(x, name):          # trunk convolution: bf16 copy of the fp32 master kernel, output (+bias) stored in bf16
+        return st(K.conv2d(x, rf(w[name + "/kernel"]), w[name + "/bias"], 1, "same"))
 
     def bn(x, name):
         if norm == "instance":          # north_star extension (no reference counterpart)
@@ -123,19 +130,20 @@ def upscaler_orig_forward(w, x_nhwc, training, res_block_num, upscale_factor, ta
 
     x = x_nhwc.permute(0, 3, 1, 2)
     m = tap("initial/prelu", K.prelu(tap("initial/conv", conv(x, "initial/conv")), w["initial/prelu/alpha"]))
-    skip = m
+    skip = rf(m)                     # long skip: bf16 copy of the fp32 tensor, its gradient stays fp32
+    m = st(m)
     for i in range(res_block_num):
         n = "res_block/%d" % i
         gen = m
-        m = tap(n + "/conv_pre", conv(m, n + "/conv_pre"))
+        m = tap(n + "/conv_pre", tconv(m, n + "/conv_pre"))
         m = bn(m, n + "/batch_norm_pre")
-        m = tap(n + "/prelu", K.prelu(m, w[n + "/prelu/alpha"]))
-        m = tap(n + "/conv_post", conv(m, n + "/conv_post"))
+        m = tap(n + "/prelu", st(K.prelu(m, w[n + "/prelu/alpha"])))
+        m = tap(n + "/conv_post", tconv(m, n + "/conv_post"))
         m = bn(m, n + "/batch_norm_post")
-        m = tap(n + "/final_add", gen + m)
-    m = conv(m, "prefinal/conv2d")
-    m = bn(m, "prefinal/batch_norm")
-    m = tap("prefinal/tanh", skip + m)                            # Add misnamed in model.py:285
+        m = tap(n + "/final_add", st(gen + m))
+    m = tconv(m, "prefinal/conv2d")
+    m = rg(bn(m, "prefinal/batch_norm"))
+    m = tap("prefinal/tanh", rf(skip + m))                        # Add misnamed in model.py:285
     for i in range(int(math.log(upscale_factor, 2))):
         n = "upscaling/%d/block" % i
         m = K.conv2d_transpose_same(m, w[n + "/conv_transp/kernel"], w[n + "/conv_transp/bias"], 2)

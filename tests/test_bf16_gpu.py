@@ -404,3 +404,66 @@ def test_norm_bwd_bf16(rt, mode, n, c, h, w, act):
     report("bf16 norm bwd %s n=%d c=%d %dx%d act=%s  %s" % (mode, n, c, h, w, act, "  ".join("%s=%.2e" % kv for kv in errs.items())))
     assert e_dx < TOL_BF16
     assert all(v < 2e-4 for k, v in errs.items() if k != "dx")
+
+
+def test_bf16_trunk_generator_training_forward_and_gradients(rt):
+    """make_upscaler_orig(..., trunk_dtype='bf16'): the residual trunk trains on bf16 activations (conv fwd / dgrad /
+    wgrad, norm fwd / bwd in bf16_*.hip) with fp32 master weights.  Training-mode forward, loss and every gradient tensor
+    against the fp64 oracle evaluated WITH THE SAME STORAGE ROUNDINGS (oracle.keras_ops.bf16_store at the tensors the
+    product keeps in bf16, values and gradients): what remains is fp32-vs-fp64 arithmetic, measured by running the same
+    emulation in fp32 (bound: 2.5x that distance, or the fp32 path's 1e-3 / 1e-2 if larger).  The distance to the un-rounded
+    fp64 oracle -- the price of bf16 storage itself -- is reported beside it."""
+    from oracle import models as M
+    from upscaler import model as PM, _engine as E
+    res, n, h, w = 2, 4, 32, 32
+    Gb = PM.make_upscaler_orig((2 * h, 2 * w, 3), kernel_size=3, upscale_factor=2, res_block_num=res, seed=7, trunk_dtype="bf16")
+    Gf = PM.make_upscaler_orig((2 * h, 2 * w, 3), kernel_size=3, upscale_factor=2, res_block_num=res, seed=7)
+    wd = _randomize_bn(Gb, 5)
+    Gf.set_weights_dict(wd)
+    x = (np.random.RandomState(1).randint(0, 256, (n, h, w, 3)) / 127.5 - 1).astype(np.float32)
+    t = (np.random.RandomState(2).randint(0, 256, (n, 2 * h, 2 * w, 3)) / 127.5 - 1).astype(np.float32)
+
+    def oracle(trunk_bf16, dt=torch.float64):
+        leaf = M.to_torch(wd, dt, requires_grad=True)
+        yr, upd = M.upscaler_orig_forward(leaf, torch.tensor(x, dtype=dt), True, res, 2, trunk_bf16=trunk_bf16)
+        loss = ((yr - torch.tensor(t, dtype=dt)) ** 2).mean()
+        names = [k for k, v in leaf.items() if v.requires_grad]
+        return yr.detach().double(), float(loss.detach()), dict(zip(names, [g.double() for g in torch.autograd.grad(loss, [leaf[k] for k in names])])), upd
+    ref = {"bf16-trunk": oracle(True), "fp32": oracle(False)}
+    # the yardstick: the SAME emulation evaluated in fp32.  With bf16 storage, fp32-vs-fp64 arithmetic no longer means 1e-6:
+    # a value within fp32 rounding of a bf16 boundary is stored as the other neighbour (one bf16 ulp), and the trunk amplifies
+    # these flips (measured: output 3e-3, gradient tensors up to 3.4e-2 in relative L2 between the two oracle runs)
+    y32, _, g32, _ = oracle(True, torch.float32)
+    out = {}
+    for tag, G in (("bf16-trunk", Gb), ("fp32", Gf)):
+        y, tape = G.forward(E.to_device_nchw(rt, x), True)
+        val, dy = PM._pixel_loss(rt, y, E.to_device_nchw(rt, t), "mse", 1.0)
+        G.backward(tape, dy, 0)
+        yr, lossr, gref, upd = ref[tag]
+        l2 = lambda a, b, floor=0.0: float((a - b).norm() / (b.norm() + floor))
+        yd = E.to_nhwc(rt, y).cpu().double()
+        e_y = l2(yd, yr)          # relative L2: a value within fp32 rounding of a bf16 rounding boundary lands on the other
+        #                           neighbour (one bf16 ulp, 4e-3 of that element) -- a handful of such elements set the max-norm
+        gmax = max(float(g.abs().max()) for g in gref.values())
+        worst, worst_plain = 0.0, 0.0
+        for k, b in gref.items():
+            a = G.ps.grad(k).cpu().double()
+            floor = 1e-4 * gmax * b.numel() ** 0.5        # conv biases in front of a BatchNormalization: (numerically) zero gradient
+            e = l2(a, b, floor)
+            worst = max(worst, e)
+            worst_plain = max(worst_plain, l2(a, ref["fp32"][2][k], floor))
+            if tag == "bf16-trunk":
+                report("    %-40s |g|2=%.2e rel L2 err=%.2e" % (k, float(b.norm()), e))
+        out[tag] = (e_y, worst, abs(float(val.item()) - lossr) / lossr)
+        if tag == "bf16-trunk":
+            e32_y = l2(y32, yr)
+            e32_g = max(l2(g32[k], b, 1e-4 * gmax * b.numel() ** 0.5) for k, b in gref.items())
+            report("    oracle fp32-with-bf16-storage vs oracle fp64-with-bf16-storage: output %.2e, worst gradient tensor %.2e" % (e32_y, e32_g))
+            assert e_y < max(1e-3, 2.5 * e32_y) and worst < max(1e-2, 2.5 * e32_g) and out[tag][2] < 1e-4, (out[tag], e32_y, e32_g)
+        report("generator training pass (%s) vs oracle with the same storage: output err (rel L2)=%.2e  worst gradient tensor (rel L2)=%.2e  loss err=%.1e"
+               "   [vs un-rounded fp64 oracle: output %.2e, gradients %.2e]"
+               % ((tag,) + out[tag] + (l2(yd, ref["fp32"][0]), worst_plain)))
+        sw = G.get_weights_dict()
+        for k, v in upd.items():                          # moving statistics: momentum 0.99, Bessel-corrected variance
+            assert np.max(np.abs(sw[k] - v.detach().numpy())) < 1e-4 * (np.max(np.abs(v.detach().numpy())) + 1e-3), k
+    assert out["fp32"][0] < 1e-3 and out["fp32"][1] < 1e-2 and out["fp32"][2] < 1e-4, out["fp32"]

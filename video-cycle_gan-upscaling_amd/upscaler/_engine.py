@@ -499,6 +499,162 @@ class Dense(Layer):
 
 
 # =================================================================================================
+# bf16-storage trunk layers (BASELINE.json configs C3/C4: bf16 activations, fp32 master weights / gradients /
+# statistics).  Activations are bf16 NHWC torch tensors [n,h,w,64]; parameter names and layouts are those of Conv2D /
+# NormAct, so a model built with them exchanges weights with the fp32 one and with the reference.
+# =================================================================================================
+def to_bf16_nhwc(rt, x_nchw):
+    n, c, h, w = x_nchw.shape
+    y = torch.empty(n, h, w, c, dtype=torch.bfloat16, device=rt.device)
+    L.check(rt.lib.vcg_f32_nchw_to_bf16_nhwc(x_nchw.data_ptr(), y.data_ptr(), n, c, h, w, rt.stream), "vcg_f32_nchw_to_bf16_nhwc")
+    return y
+
+
+def from_bf16_nhwc(rt, x_nhwc):
+    n, h, w, c = x_nhwc.shape
+    y = rt.empty(n, c, h, w)
+    L.check(rt.lib.vcg_bf16_nhwc_to_f32_nchw(x_nhwc.data_ptr(), y.data_ptr(), n, c, h, w, rt.stream), "vcg_bf16_nhwc_to_f32_nchw")
+    return y
+
+
+class Conv3x3Bf16(Layer):
+    """Conv2D(64, 3, 'same') on bf16 NHWC: forward and data gradient on vcg_conv2d_bf16_fwd (the latter with the kernel
+    packed tap-flipped and transposed), weight / bias gradient on vcg_conv2d_bf16_wgrad (fp32, into the master gradient)."""
+
+    def __init__(self, name, cin=64, cout=64):
+        super().__init__(name)
+        if cin != 64 or cout != 64:
+            raise NotImplementedError("the bf16 trunk convolution is instantiated for 64 -> 64 channels")
+        self.cin, self.cout, self.k = cin, cout, 3
+        self._wf = self._wd = None
+        self._valid = False
+
+    def declare(self, ps):
+        ps.declare(self.name + "/kernel", (3, 3, self.cin, self.cout))
+        ps.declare(self.name + "/bias", (self.cout,))
+
+    def init_weights(self, rng):
+        return {self.name + "/kernel": glorot_uniform(rng, (3, 3, self.cin, self.cout), 9 * self.cin, 9 * self.cout),
+                self.name + "/bias": np.zeros((self.cout,), np.float32)}
+
+    def refresh(self):
+        self._valid = False
+
+    def _packed(self):
+        rt = self.rt
+        if self._wf is None:
+            self._wf = torch.empty(9, 64, 64, dtype=torch.bfloat16, device=rt.device)
+            self._wd = torch.empty(9, 64, 64, dtype=torch.bfloat16, device=rt.device)
+        if not self._valid:
+            w = self.ps[self.name + "/kernel"].data_ptr()
+            L.check(rt.lib.vcg_pack_conv_kernel_bf16(w, 9, 64, 64, 1, 0, self._wf.data_ptr(), rt.stream), "pack fwd")      # [tap][co][ci]
+            L.check(rt.lib.vcg_pack_conv_kernel_bf16(w, 9, 64, 64, 0, 1, self._wd.data_ptr(), rt.stream), "pack dgrad")    # [tap'][ci][co]
+            self._valid = True
+        return self._wf, self._wd
+
+    def _run(self, x, w, bias, residual=None):
+        rt = self.rt
+        n, h, wd, _ = x.shape
+        y = torch.empty(n, h, wd, 64, dtype=torch.bfloat16, device=rt.device)
+        d = L.ConvDesc(n, 64, h, wd, 64, h, wd, 3, 3, 1, 1, 1)
+        ep = L.EpilogueBf16(None, bias, L.ACT_NONE, 0.0, None, _ptr(residual))
+        L.check(rt.lib.vcg_conv2d_bf16_fwd(ctypes.byref(d), x.data_ptr(), w.data_ptr(), y.data_ptr(), ctypes.byref(ep), rt.stream),
+                "vcg_conv2d_bf16_fwd[%s]" % self.name)
+        return y, d
+
+    def forward(self, x, tag=None):
+        wf, _ = self._packed()
+        with Timed(self.rt, tag):
+            y, d = self._run(x, wf, self.ps[self.name + "/bias"].data_ptr())
+        return y, (x, d)
+
+    def backward(self, ctx, dy, need_dx=True, param_grads=True, which=0, dx_residual=None, tag=None):
+        """dx_residual: a gradient that joins at this layer's input (the block's skip branch), added in the epilogue"""
+        rt = self.rt
+        x, d = ctx
+        if param_grads:
+            ws, wsn = rt.workspace(rt.lib.vcg_conv2d_bf16_wgrad_workspace_bytes(ctypes.byref(d)))
+            with Timed(rt, tag and tag + "_wgrad"):
+                L.check(rt.lib.vcg_conv2d_bf16_wgrad(ctypes.byref(d), x.data_ptr(), dy.data_ptr(), self.ps.grad(self.name + "/kernel", which).data_ptr(),
+                                                     self.ps.grad(self.name + "/bias", which).data_ptr(), ws, wsn, rt.stream),
+                        "vcg_conv2d_bf16_wgrad[%s]" % self.name)
+        if not need_dx:
+            return None
+        _, wdg = self._packed()
+        with Timed(rt, tag and tag + "_dgrad"):
+            dx, _ = self._run(dy, wdg, None, dx_residual)
+        return dx
+
+
+class NormActBf16(Layer):
+    """NormAct on bf16 NHWC (same parameters / names): statistics, affine and activation arithmetic in fp32."""
+
+    def __init__(self, name, c, norm="batch", act=L.ACT_NONE, alpha=0.0, prelu_name=None):
+        super().__init__(name)
+        if norm not in ("batch", "instance"):
+            raise ValueError(norm)
+        self.c, self.norm, self.act, self.alpha, self.prelu_name = c, norm, act, alpha, prelu_name
+
+    declare = NormAct.declare
+    init_weights = NormAct.init_weights
+    _alpha_ptr = NormAct._alpha_ptr
+
+    def forward(self, x, training, residual=None, update_moving=True):
+        rt, ps, lib = self.rt, self.ps, self.rt.lib
+        n, h, w, c = x.shape
+        hw = h * w
+        inst = self.norm == "instance"
+        rows = n if inst else 1
+        mode = L.NORM_INSTANCE if inst else L.NORM_BATCH
+        scale, shift, invstd = rt.empty(rows * c), rt.empty(rows * c), rt.empty(rows * c)
+        gamma = None if inst else ps[self.name + "/gamma"].data_ptr()
+        beta = None if inst else ps[self.name + "/beta"].data_ptr()
+        saved = None
+        if training or inst:
+            mean, var = rt.empty(rows * c), rt.empty(rows * c)
+            ws, wsn = rt.workspace(lib.vcg_norm_stats_bf16_workspace_bytes(n, c, hw, mode))
+            L.check(lib.vcg_norm_stats_bf16(x.data_ptr(), n, c, hw, mode, mean.data_ptr(), var.data_ptr(), ws, wsn, rt.stream),
+                    "vcg_norm_stats_bf16[%s]" % self.name)
+            mm = mv = None
+            if not inst and update_moving:
+                mm, mv = ps[self.name + "/moving_mean"].data_ptr(), ps[self.name + "/moving_variance"].data_ptr()
+            L.check(lib.vcg_norm_finalize(mean.data_ptr(), var.data_ptr(), gamma, beta, c, rows, IN_EPS if inst else BN_EPS, scale.data_ptr(),
+                                          shift.data_ptr(), invstd.data_ptr(), mm, mv, BN_MOMENTUM, 0 if inst else n * hw, rt.stream),
+                    "vcg_norm_finalize")
+            saved = (mean, invstd)
+        else:
+            L.check(lib.vcg_norm_finalize(ps[self.name + "/moving_mean"].data_ptr(), ps[self.name + "/moving_variance"].data_ptr(), gamma, beta, c, 1,
+                                          BN_EPS, scale.data_ptr(), shift.data_ptr(), invstd.data_ptr(), None, None, 0.0, 0, rt.stream),
+                    "vcg_norm_finalize")
+        y = torch.empty_like(x)
+        L.check(lib.vcg_norm_act_fwd_bf16(x.data_ptr(), n, c, hw, scale.data_ptr(), shift.data_ptr(), 1 if inst else 0, self.act, float(self.alpha),
+                                          self._alpha_ptr(), _ptr(residual), y.data_ptr(), rt.stream), "vcg_norm_act_fwd_bf16[%s]" % self.name)
+        return y, (x, saved, mode, (n, c, hw))
+
+    def backward(self, ctx, dy, param_grads=True, which=0):
+        rt, ps, lib = self.rt, self.ps, self.rt.lib
+        x, saved, mode, (n, c, hw) = ctx
+        if saved is None:
+            raise RuntimeError("backward through inference-mode normalisation is not defined")
+        mean, invstd = saved
+        inst = self.norm == "instance"
+        gamma = None if inst else ps[self.name + "/gamma"].data_ptr()
+        beta = None if inst else ps[self.name + "/beta"].data_ptr()
+        dgamma = dbeta = dalpha = None
+        if param_grads:
+            if not inst:
+                dgamma, dbeta = ps.grad(self.name + "/gamma", which).data_ptr(), ps.grad(self.name + "/beta", which).data_ptr()
+            if self.act == L.ACT_PRELU:
+                dalpha = ps.grad(self.prelu_name + "/alpha", which).data_ptr()
+        dx = torch.empty_like(x)
+        ws, wsn = rt.workspace(lib.vcg_norm_act_bwd_bf16_workspace_bytes(n, c, hw, mode))
+        L.check(lib.vcg_norm_act_bwd_bf16(x.data_ptr(), dy.data_ptr(), n, c, hw, mode, mean.data_ptr(), invstd.data_ptr(), gamma, beta, self.act,
+                                          float(self.alpha), self._alpha_ptr(), 1, dx.data_ptr(), dgamma, dbeta, dalpha, ws, wsn, rt.stream),
+                "vcg_norm_act_bwd_bf16[%s]" % self.name)
+        return dx
+
+
+# =================================================================================================
 # layout helpers at the API edge
 # =================================================================================================
 def to_device_nchw(rt, x):

@@ -401,9 +401,17 @@ class VGG19Features(Model):
 class UpscalerOrig(Model):
     """make_upscaler_orig topology (model.py:267-295)."""
 
-    def __init__(self, output_image_shape, kernel_size, filters, upscale_factor, res_block_num, norm, seed):
+    def __init__(self, output_image_shape, kernel_size, filters, upscale_factor, res_block_num, norm, seed, trunk_dtype="fp32"):
         f = upscale_factor
         super().__init__("upscaler_orig", (output_image_shape[0] // f, output_image_shape[1] // f, output_image_shape[2]), seed)
+        if trunk_dtype not in ("fp32", "bf16"):
+            raise ValueError(trunk_dtype)
+        if trunk_dtype == "bf16" and (kernel_size != 3 or filters != 64):
+            raise NotImplementedError("the bf16 trunk is instantiated for kernel_size=3, filters=64")
+        self.trunk_dtype = trunk_dtype
+        bf = trunk_dtype == "bf16"
+        conv = (lambda n, ci, co, kk: E.Conv3x3Bf16(n, ci, co)) if bf else (lambda n, ci, co, kk: E.Conv2D(n, ci, co, kk))
+        normact = E.NormActBf16 if bf else E.NormAct
         self.upscale_times = int(math.log(f, 2))
         self.factor = 2 ** self.upscale_times
         k = kernel_size
@@ -414,13 +422,13 @@ class UpscalerOrig(Model):
         for i in range(res_block_num):
             n = "res_block/%d" % i
             self.blocks.append((
-                self._add(E.Conv2D(n + "/conv_pre", filters, filters, k)),
-                self._add(E.NormAct(n + "/batch_norm_pre", filters, nrm, L.ACT_PRELU, prelu_name=n + "/prelu")),
-                self._add(E.Conv2D(n + "/conv_post", filters, filters, k)),
-                self._add(E.NormAct(n + "/batch_norm_post", filters, nrm)),
+                self._add(conv(n + "/conv_pre", filters, filters, k)),
+                self._add(normact(n + "/batch_norm_pre", filters, nrm, L.ACT_PRELU, prelu_name=n + "/prelu")),
+                self._add(conv(n + "/conv_post", filters, filters, k)),
+                self._add(normact(n + "/batch_norm_post", filters, nrm)),
             ))
-        self.c_pre = self._add(E.Conv2D("prefinal/conv2d", filters, 64, k))          # 64: model.py:283
-        self.n_pre = self._add(E.NormAct("prefinal/batch_norm", 64, nrm))
+        self.c_pre = self._add(conv("prefinal/conv2d", filters, 64, k))               # 64: model.py:283
+        self.n_pre = self._add(normact("prefinal/batch_norm", 64, nrm))
         self.ups = []
         cin = 64
         for i in range(self.upscale_times):
@@ -441,6 +449,8 @@ class UpscalerOrig(Model):
         tape = []
         h, c = self.c_init.forward(x); tape.append(c)
         h, c = self.a_init.forward(h, training); tape.append(c)
+        if self.trunk_dtype == "bf16":          # the trunk (2*res+1 convolutions, norms, adds) on bf16 NHWC; fp32 outside
+            h = E.to_bf16_nhwc(self.rt, h)
         skip = h
         for (c1, n1, c2, n2) in self.blocks:
             gen = h
@@ -450,6 +460,8 @@ class UpscalerOrig(Model):
             h, a = n2.forward(h, training, residual=gen); tape.append(a)
         h, a = self.c_pre.forward(h, tag="trunk_conv"); tape.append(a)
         h, a = self.n_pre.forward(h, training, residual=skip); tape.append(a)
+        if self.trunk_dtype == "bf16":
+            h = E.from_bf16_nhwc(self.rt, h)
         for u in self.ups:
             h, a = u.forward(h, tag="convt"); tape.append(a)
         h, a = self.c_fin.forward(h, tag="final_conv"); tape.append(a)
@@ -464,6 +476,8 @@ class UpscalerOrig(Model):
             d = u.backward(tape.pop(), d, True, True, which, tag="convt")
         # s = skip + BN(conv(h)):  d flows to both
         dskip = d
+        if self.trunk_dtype == "bf16":
+            d = E.to_bf16_nhwc(rt, d)
         d = self.n_pre.backward(tape.pop(), d, True, which)
         d = self.c_pre.backward(tape.pop(), d, True, True, which, tag="trunk_conv")
         for (c1, n1, c2, n2) in reversed(self.blocks):
@@ -473,6 +487,8 @@ class UpscalerOrig(Model):
             d = n1.backward(tape.pop(), d, True, which)
             d = c1.backward(tape.pop(), d, True, True, which, dx_residual=dres, tag="trunk_conv")
         # d is now dL/d(a_init output) from the trunk; add the long-skip gradient
+        if self.trunk_dtype == "bf16":
+            d = E.from_bf16_nhwc(rt, d)
         E.axpby(rt, dskip, d, 1.0, 1.0)
         d = self.a_init.backward(tape.pop(), d, True, which)
         self.c_init.backward(tape.pop(), d, False, True, which)
@@ -604,11 +620,12 @@ class DiscriminatorPatchGAN(Model):
 # factories -- reference signatures
 # =================================================================================================
 def make_upscaler_orig(output_image_shape, kernel_size=5, filters=64, upscale_factor=4, res_block_num=16,
-                       norm="batch", seed=7):
-    """model.py:267-295.  ``norm='instance'`` and ``seed`` are extensions (keyword-only in spirit)."""
+                       norm="batch", seed=7, trunk_dtype="fp32"):
+    """model.py:267-295.  ``norm='instance'``, ``seed`` and ``trunk_dtype`` are extensions (keyword-only in spirit);
+    ``trunk_dtype='bf16'`` keeps the residual trunk's activations in bf16 (fp32 master weights, gradients, statistics)."""
     if upscale_factor < 1 or (upscale_factor & (upscale_factor - 1)) != 0:
         raise ValueError("upscale_factor must be a power of two (train_gan3.py:120-122)")
-    return UpscalerOrig(tuple(output_image_shape), kernel_size, filters, upscale_factor, res_block_num, norm, seed)
+    return UpscalerOrig(tuple(output_image_shape), kernel_size, filters, upscale_factor, res_block_num, norm, seed, trunk_dtype)
 
 
 def make_discriminator_simple_512(input_shape, activation="none", seed=11):
