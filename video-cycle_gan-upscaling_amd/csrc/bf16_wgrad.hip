@@ -57,7 +57,8 @@ constexpr int G_WAVE_FLOATS = 12 * 16 * 64;            // a wave's partial block
 struct WgParams {
     const unsigned char* x;      // bf16 NHWC [n][h][w][64]
     const unsigned char* dy;     // bf16 NHWC [n][h][w][64]
-    float* ws;                   // [grid][6][G_WAVE_FLOATS]
+    float* ws;                   // [grid][3 tap rows][G_WAVE_FLOATS]
+    float* wsb;                  // [grid][2][2][64] bias partials
     int n, h, w_, tiles_x, tiles_y, total;
 };
 
@@ -86,6 +87,7 @@ __global__ __launch_bounds__(G_NW * 64, 1) void wgrad3x3_c64_bf16_kernel(WgParam
                 bbase[dx][cih][ip] = (unsigned)(G_DYB + (dyi * G_XP + h8 + q + dx) * 128 + ((64 * cih + chb) ^ (64 * sb)));
             }
 
+    float dbs[2] = {0.f, 0.f};              // bias gradient: this lane's channel (of each co half), its 8 pixels per k-step
     f32x16 acc[3][2][2];
 #pragma unroll
     for (int a = 0; a < 3; ++a)
@@ -145,6 +147,16 @@ __global__ __launch_bounds__(G_NW * 64, 1) void wgrad3x3_c64_bf16_kernel(WgParam
                          : "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[1][0]), "+v"(fa[1][1]), "+v"(fb[0][0][0]), "+v"(fb[0][0][1]),
                            "+v"(fb[0][1][0]), "+v"(fb[0][1][1]), "+v"(fb[1][0][0]), "+v"(fb[1][0][1]), "+v"(fb[1][1][0]), "+v"(fb[1][1][1]),
                            "+v"(fb[2][0][0]), "+v"(fb[2][0][1]), "+v"(fb[2][1][0]), "+v"(fb[2][1][1]));
+            if (dyi == 0) {                         // wave-uniform: the two tap-row-0 waves cover every pixel once
+#pragma unroll
+                for (int coh = 0; coh < 2; ++coh)
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+                        const bf16x4 v4 = __builtin_bit_cast(bf16x4, fa[coh][t]);
+                        dbs[coh] += ((float)v4[0] + (float)v4[1]) + ((float)v4[2] + (float)v4[3]);
+                    }
+            }
 #pragma unroll
             for (int dx = 0; dx < 3; ++dx)
 #pragma unroll
@@ -161,16 +173,40 @@ __global__ __launch_bounds__(G_NW * 64, 1) void wgrad3x3_c64_bf16_kernel(WgParam
         });
     }
 
-    // this wave's partial block: raw register dump (coalesced), decoded by the reduction
-    float* out = p.ws + ((long)blockIdx.x * G_NW + wv) * G_WAVE_FLOATS;
+    // the two pixel-half waves of a tap row add their blocks through LDS (the stage buffers are free now): one raw
+    // register dump per tap row and workgroup (coalesced), decoded by the reduction
+    lds_barrier();
+    float* xch = (float*)smem + dyi * G_WAVE_FLOATS;               // 3 x 48 KiB
+    if (ph == 1) {
 #pragma unroll
-    for (int dx = 0; dx < 3; ++dx)
+        for (int dx = 0; dx < 3; ++dx)
 #pragma unroll
-        for (int cih = 0; cih < 2; ++cih)
+            for (int cih = 0; cih < 2; ++cih)
 #pragma unroll
-            for (int coh = 0; coh < 2; ++coh)
+                for (int coh = 0; coh < 2; ++coh)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) out[(((dx * 2 + cih) * 2 + coh) * 16 + e) * 64 + lane] = acc[dx][cih][coh][e];
+                    for (int e = 0; e < 16; ++e) xch[(((dx * 2 + cih) * 2 + coh) * 16 + e) * 64 + lane] = acc[dx][cih][coh][e];
+    }
+    lds_barrier();
+    if (ph == 0) {
+        float* out = p.ws + ((long)blockIdx.x * 3 + dyi) * G_WAVE_FLOATS;
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+            for (int cih = 0; cih < 2; ++cih)
+#pragma unroll
+                for (int coh = 0; coh < 2; ++coh)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int o = (((dx * 2 + cih) * 2 + coh) * 16 + e) * 64 + lane;
+                        out[o] = acc[dx][cih][coh][e] + xch[o];
+                    }
+    }
+    if (dyi == 0) {                                 // bias partials: [workgroup][pixel half][lane half][64 channels]
+        float* bo = p.wsb + (((long)blockIdx.x * 2 + ph) * 2 + (lane >> 5)) * 64;
+        bo[lane & 31] = dbs[0];
+        bo[32 + (lane & 31)] = dbs[1];
+    }
 }
 
 // dW[tap = dyi*3+dx][ci][co] = sum over workgroups and the two pixel-half waves of tap row dyi, in a fixed order
@@ -183,43 +219,27 @@ __global__ void wgrad3x3_c64_reduce_kernel(const float* __restrict__ ws, int nbl
     const int hsel = (cr >> 2) & 1, e = (cr & 3) + 4 * (cr >> 3), l = (ci & 31) + 32 * hsel;
     const long off = ((((long)dx * 2 + cih) * 2 + coh) * 16 + e) * 64 + l;
     float s = 0.f;
-    for (int b = 0; b < nblocks; ++b)
-        for (int ph = 0; ph < 2; ++ph) s += ws[((long)b * G_NW + dyi * 2 + ph) * G_WAVE_FLOATS + off];
+    for (int b = 0; b < nblocks; ++b) s += ws[((long)b * 3 + dyi) * G_WAVE_FLOATS + off];
     dw[idx] = s;
 }
 
-__global__ __launch_bounds__(256) void bias_grad_bf16_kernel(const bf16x8* __restrict__ dy, long pixels, float* __restrict__ part) {
-    // 64 channels: thread = (pixel lane 0..31, 8-channel chunk 0..7); per-block partial sums, reduced by the caller's second pass
-    __shared__ float red[256 * 8];
-    const int ch = threadIdx.x & 7, pl = threadIdx.x >> 3;
-    float s[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) s[j] = 0.f;
-    for (long px = (long)blockIdx.x * 32 + pl; px < pixels; px += (long)gridDim.x * 32) {
-        const bf16x8 v = dy[px * 8 + ch];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) s[j] += (float)v[j];
-    }
-#pragma unroll
-    for (int j = 0; j < 8; ++j) red[threadIdx.x * 8 + j] = s[j];
+__global__ __launch_bounds__(1024) void wgrad3x3_c64_bias_reduce_kernel(const float* __restrict__ wsb, int nblocks, float* __restrict__ db) {
+    // 16 row groups x 64 channels; fixed order within a group and across groups
+    __shared__ float red[16][64];
+    const int c = threadIdx.x & 63, g = threadIdx.x >> 6, rows = nblocks * 4;
+    float s = 0.f;
+    for (int b = g; b < rows; b += 16) s += wsb[(long)b * 64 + c];
+    red[g][c] = s;
     __syncthreads();
-    if (threadIdx.x < 64) {
+    if (g == 0) {
         float t = 0.f;
-        for (int l = 0; l < 32; ++l) t += red[(l * 8 + (threadIdx.x >> 3)) * 8 + (threadIdx.x & 7)];
-        part[(long)blockIdx.x * 64 + threadIdx.x] = t;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) t += red[i][c];
+        db[c] = t;
     }
-}
-
-__global__ void bias_grad_final_kernel(const float* __restrict__ part, int nblocks, float* __restrict__ db) {
-    const int c = threadIdx.x;
-    if (c >= 64) return;
-    double s = 0.0;
-    for (int b = 0; b < nblocks; ++b) s += part[(long)b * 64 + c];
-    db[c] = (float)s;
 }
 
 constexpr int G_GRID = 256;
-constexpr int G_BIAS_BLOCKS = 512;
 
 }  // namespace
 
@@ -227,7 +247,7 @@ extern "C" {
 
 size_t vcg_conv2d_bf16_wgrad_workspace_bytes(const vcg_conv_desc* d) {
     if (!d) return 0;
-    return (size_t)G_GRID * G_NW * G_WAVE_FLOATS * sizeof(float) + (size_t)G_BIAS_BLOCKS * 64 * sizeof(float);
+    return (size_t)G_GRID * 3 * G_WAVE_FLOATS * sizeof(float) + (size_t)G_GRID * 4 * 64 * sizeof(float);
 }
 
 int vcg_conv2d_bf16_wgrad(const vcg_conv_desc* d, const void* x, const void* dy, float* dw_hwio, float* dbias, void* ws, size_t ws_bytes,
@@ -240,6 +260,7 @@ int vcg_conv2d_bf16_wgrad(const vcg_conv_desc* d, const void* x, const void* dy,
     p.x = (const unsigned char*)x;
     p.dy = (const unsigned char*)dy;
     p.ws = (float*)ws;
+    p.wsb = (float*)ws + (size_t)G_GRID * 3 * G_WAVE_FLOATS;
     p.n = d->n; p.h = d->h; p.w_ = d->w;
     p.tiles_x = ceil_div(d->w, G_C);
     p.tiles_y = ceil_div(d->h, G_R);
@@ -256,12 +277,7 @@ int vcg_conv2d_bf16_wgrad(const vcg_conv_desc* d, const void* x, const void* dy,
     wgrad3x3_c64_reduce_kernel<<<(9 * 64 * 64 + 255) / 256, 256, 0, stream>>>((const float*)ws, grid, dw_hwio);
     VCG_LAUNCH_CHECK();
     if (dbias) {
-        float* part = (float*)ws + (size_t)G_GRID * G_NW * G_WAVE_FLOATS;
-        const long pixels = (long)d->n * d->h * d->w;
-        const int nb = (int)(pixels / 32 < G_BIAS_BLOCKS ? (pixels + 31) / 32 : G_BIAS_BLOCKS);
-        bias_grad_bf16_kernel<<<nb, 256, 0, stream>>>((const bf16x8*)dy, pixels, part);
-        VCG_LAUNCH_CHECK();
-        bias_grad_final_kernel<<<1, 64, 0, stream>>>(part, nb, dbias);
+        wgrad3x3_c64_bias_reduce_kernel<<<1, 1024, 0, stream>>>(p.wsb, grid, dbias);
         VCG_LAUNCH_CHECK();
     }
     return VCG_OK;
