@@ -101,9 +101,14 @@ __global__ __launch_bounds__(G_NW * 64, 1) void wgrad3x3_c64_bf16_kernel(WgParam
     auto dma = [&](int tile, int buf) {
         const int txi = tile % p.tiles_x, t2 = tile / p.tiles_x, tyi = t2 % p.tiles_y, img = t2 / p.tiles_y;
         const int y0 = tyi * G_R, x0 = txi * G_C;
+        // The slot -> address arithmetic is redone for every tile on purpose: hoisted out of the tile loop it costs 40
+        // VGPRs the kernel does not have (192 are accumulators), the spills come back as scratch loads, and a scratch load
+        // shares vmcnt with the DMA -- every reload would wait for the previous global_load_lds to land (measured: 8x slower)
+        int tid_o = tid;
+        asm volatile("" : "+v"(tid_o));
 #pragma unroll
         for (int k = 0; k < G_NDMA; ++k) {
-            const int s = min(k * (G_NW * 64) + tid, G_CHUNKS - 1);          // the tail re-fetches the last chunk into its own slot
+            const int s = min(k * (G_NW * 64) + tid_o, G_CHUNKS - 1);        // the tail re-fetches the last chunk into its own slot
             const bool isx = s >= G_DYB / 16;
             const int sl = isx ? s - G_DYB / 16 : s;
             const int P = sl >> 3, cs = (sl & 7) ^ (4 * ((P >> 1) & 1));     // stored chunk (sl&7) holds source chunk cs
@@ -209,18 +214,25 @@ __global__ __launch_bounds__(G_NW * 64, 1) void wgrad3x3_c64_bf16_kernel(WgParam
     }
 }
 
-// dW[tap = dyi*3+dx][ci][co] = sum over workgroups and the two pixel-half waves of tap row dyi, in a fixed order
+// dW[tap = dyi*3+dx][ci][co] = sum over workgroups, in a fixed order.  One thread per element of a tap row's raw block (reads
+// coalesced in the dump's own order), the decoded (tap, ci, co) position is only used for the single store.
 __global__ void wgrad3x3_c64_reduce_kernel(const float* __restrict__ ws, int nblocks, float* __restrict__ dw) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;             // output element, Keras (3,3,64 ci,64 co) order
-    if (idx >= 9 * 64 * 64) return;
-    const int co = idx & 63, ci = (idx >> 6) & 63, tap = idx >> 12, dyi = tap / 3, dx = tap - 3 * dyi;
-    const int coh = co >> 5, cr = co & 31, cih = ci >> 5;
-    // D[row = co in block][col = ci in block]: register e, lane l with row = (e&3) + 8*(e>>2) + 4*(l>>5), col = l&31
-    const int hsel = (cr >> 2) & 1, e = (cr & 3) + 4 * (cr >> 3), l = (ci & 31) + 32 * hsel;
-    const long off = ((((long)dx * 2 + cih) * 2 + coh) * 16 + e) * 64 + l;
-    float s = 0.f;
-    for (int b = 0; b < nblocks; ++b) s += ws[((long)b * 3 + dyi) * G_WAVE_FLOATS + off];
-    dw[idx] = s;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;             // (dyi, raw offset)
+    if (idx >= 3 * G_WAVE_FLOATS) return;
+    const int dyi = idx / G_WAVE_FLOATS, off = idx - dyi * G_WAVE_FLOATS;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int b = 0;
+    for (; b + 3 < nblocks; b += 4) {
+        s0 += ws[((long)(b + 0) * 3 + dyi) * G_WAVE_FLOATS + off];
+        s1 += ws[((long)(b + 1) * 3 + dyi) * G_WAVE_FLOATS + off];
+        s2 += ws[((long)(b + 2) * 3 + dyi) * G_WAVE_FLOATS + off];
+        s3 += ws[((long)(b + 3) * 3 + dyi) * G_WAVE_FLOATS + off];
+    }
+    for (; b < nblocks; ++b) s0 += ws[((long)b * 3 + dyi) * G_WAVE_FLOATS + off];
+    // raw offset -> tile (dx, ci half, co half), register e, lane l;  D[row][col]: row = (e&3) + 8*(e>>2) + 4*(l>>5), col = l&31
+    const int l = off & 63, e = (off >> 6) & 15, tile = off >> 10, coh = tile & 1, cih = (tile >> 1) & 1, dx = tile >> 2;
+    const int co = 32 * coh + (e & 3) + 8 * (e >> 2) + 4 * (l >> 5), ci = 32 * cih + (l & 31);
+    dw[((dyi * 3 + dx) * 64 + ci) * 64 + co] = (s0 + s1) + (s2 + s3);
 }
 
 __global__ __launch_bounds__(1024) void wgrad3x3_c64_bias_reduce_kernel(const float* __restrict__ wsb, int nblocks, float* __restrict__ db) {
@@ -274,7 +286,7 @@ int vcg_conv2d_bf16_wgrad(const vcg_conv_desc* d, const void* x, const void* dy,
     const int grid = p.total < G_GRID ? p.total : G_GRID;
     wgrad3x3_c64_bf16_kernel<<<grid, G_NW * 64, 2 * G_BUF, stream>>>(p);
     VCG_LAUNCH_CHECK();
-    wgrad3x3_c64_reduce_kernel<<<(9 * 64 * 64 + 255) / 256, 256, 0, stream>>>((const float*)ws, grid, dw_hwio);
+    wgrad3x3_c64_reduce_kernel<<<(3 * G_WAVE_FLOATS + 255) / 256, 256, 0, stream>>>((const float*)ws, grid, dw_hwio);
     VCG_LAUNCH_CHECK();
     if (dbias) {
         wgrad3x3_c64_bias_reduce_kernel<<<1, 1024, 0, stream>>>(p.wsb, grid, dbias);
