@@ -120,8 +120,11 @@ def main():
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d"
                          % (args.gpus, world, args.gpus))
-    torch.cuda.set_device(local_rank)
-    group = _dist.init_from_env("nccl") if world > 1 else None
+    # VCG_BENCH_REHEARSAL=1: run the N-rank code path on a box with fewer GPUs than ranks (all ranks on cuda:0, gloo
+    # instead of RCCL).  For rehearsing the launcher / capture / reduction logic only -- its numbers mean nothing.
+    rehearsal = os.environ.get("VCG_BENCH_REHEARSAL") == "1"
+    torch.cuda.set_device(0 if rehearsal else local_rank)
+    group = _dist.init_from_env("gloo" if rehearsal else "nccl") if world > 1 else None
 
     h = args.lr_size
     G = PM.make_upscaler_orig((2 * h, 2 * h, 3), kernel_size=3, upscale_factor=2, res_block_num=args.res_blocks, seed=7,
@@ -163,7 +166,7 @@ def main():
             print("graph capture failed (%s: %s); running eagerly" % (type(e).__name__, e), file=sys.stderr)
             use_graph = False
         if group is not None:       # all ranks must take the same path
-            ok = torch.tensor([1 if use_graph else 0], dtype=torch.int32, device=rt.device)
+            ok = torch.tensor([1 if use_graph else 0], dtype=torch.int32, device="cpu" if rehearsal else rt.device)
             dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
             use_graph = bool(ok.item())
         if use_graph:
@@ -192,7 +195,7 @@ def main():
         roof_note = ("the timed region replays one hipGraph per step, which cannot be bracketed per kernel; these are HIP-event "
                      "timings of the same launches in 3 eager steps of the same workload run right after it")
 
-    dt_t = torch.tensor([dt], dtype=torch.float64, device=rt.device)
+    dt_t = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearsal else rt.device)
     if group is not None:
         dist.all_reduce(dt_t, op=dist.ReduceOp.MAX, group=group)
     dt = float(dt_t.item())
