@@ -56,49 +56,68 @@ __global__ __launch_bounds__(256) void stats_partial_bf16_kernel(const bf16x8* _
     }
 }
 
-__global__ void stats_final_bf16_kernel(const __bf16* __restrict__ x, const float* __restrict__ part, int c, long group_pixels,
-                                        int slabs_per_group, int groups, float* __restrict__ mean, float* __restrict__ var) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;      // (group, channel)
-    if (i >= groups * c) return;
-    const int grp = i / c, ch = i - grp * c;
+// block = (group, 64 channels): 16 row groups sum the slabs in a fixed interleaved order, then one fixed-order combine
+__global__ __launch_bounds__(1024) void stats_final_bf16_kernel(const __bf16* __restrict__ x, const float* __restrict__ part, int c, long group_pixels,
+                                                                 int slabs_per_group, int groups, float* __restrict__ mean, float* __restrict__ var) {
+    __shared__ double rs[16][64], rq[16][64];
+    const int cblocks = (c + 63) / 64, grp = blockIdx.x / cblocks, ch = (blockIdx.x - grp * cblocks) * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
     double s = 0.0, q = 0.0;
-    for (int b = 0; b < slabs_per_group; ++b) {
-        const float* pp = part + (((long)grp * slabs_per_group + b) * c + ch) * 2;
-        s += pp[0];
-        q += pp[1];
-    }
+    if (ch < c)
+        for (int b = g; b < slabs_per_group; b += 16) {
+            const float* pp = part + (((long)grp * slabs_per_group + b) * c + ch) * 2;
+            s += pp[0];
+            q += pp[1];
+        }
+    rs[g][threadIdx.x & 63] = s;
+    rq[g][threadIdx.x & 63] = q;
+    __syncthreads();
+    if (g != 0 || ch >= c) return;
+#pragma unroll
+    for (int i = 1; i < 16; ++i) { s += rs[i][threadIdx.x]; q += rq[i][threadIdx.x]; }
     const double k = (double)(float)x[(long)grp * group_pixels * c + ch];
     const double m = s / (double)group_pixels;
-    mean[i] = (float)(k + m);
+    mean[grp * c + ch] = (float)(k + m);
     const double v = q / (double)group_pixels - m * m;
-    var[i] = (float)(v > 0.0 ? v : 0.0);
+    var[grp * c + ch] = (float)(v > 0.0 ? v : 0.0);
 }
 
-__global__ __launch_bounds__(256) void norm_act_fwd_bf16_kernel(const bf16x8* __restrict__ x, long total8, int c8, long pix_per_img,
+constexpr int APB = 512;        // pixels per block of the apply passes
+
+// y = act(x*scale + shift) + residual.  block = (image, APB pixels); a thread keeps ITS 8 channels' parameters in registers
+// and walks the pixels (the first version re-read 64-128 bytes of parameters for every 16 bytes of data: 1.7 TB/s)
+__global__ __launch_bounds__(256) void norm_act_fwd_bf16_kernel(const bf16x8* __restrict__ x, int c8, long pix_per_img, int blocks_per_img,
                                                                  const float* __restrict__ scale, const float* __restrict__ shift,
                                                                  int per_sample, int act, float alpha, const float* __restrict__ prelu,
                                                                  const bf16x8* __restrict__ res, bf16x8* __restrict__ y) {
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= total8) return;
-    const int ch = (int)(i % c8) * 8;
-    const long img = per_sample ? i / (pix_per_img * c8) : 0;
-    const float* sc = scale + img * c8 * 8 + ch;
-    const float* sh = shift + img * c8 * 8 + ch;
-    const bf16x8 v = x[i];
-    bf16x8 r8;
-    if (res) r8 = res[i];
-    bf16x8 o;
+    const int img = blockIdx.x / blocks_per_img, pb = blockIdx.x - img * blocks_per_img;
+    const int ch = threadIdx.x % c8, pl = threadIdx.x / c8, npl = 256 / c8;
+    if (pl >= npl) return;
+    const int pidx = (per_sample ? img * c8 * 8 : 0) + ch * 8;
+    float sc[8], sh[8], sl[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        float u = (float)v[j] * sc[j] + sh[j];
-        if (act == VCG_ACT_PRELU) u = u > 0.f ? u : u * prelu[ch + j];
-        else if (act == VCG_ACT_LRELU) u = u > 0.f ? u : u * alpha;
-        if (res) u += (float)r8[j];
-        o[j] = (__bf16)u;
+        sc[j] = scale[pidx + j];
+        sh[j] = shift[pidx + j];
+        sl[j] = act == VCG_ACT_PRELU ? prelu[ch * 8 + j] : (act == VCG_ACT_LRELU ? alpha : 1.f);
     }
-    y[i] = o;
+    const long p0 = (long)pb * APB, p1 = p0 + APB < pix_per_img ? p0 + APB : pix_per_img;
+    const long base = (long)img * pix_per_img * c8;
+    for (long p = p0 + pl; p < p1; p += npl) {
+        const long i = base + p * c8 + ch;
+        const bf16x8 v = x[i];
+        bf16x8 r8;
+        if (res) r8 = res[i];
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float u = (float)v[j] * sc[j] + sh[j];
+            u = u > 0.f ? u : u * sl[j];
+            if (res) u += (float)r8[j];
+            o[j] = (__bf16)u;
+        }
+        y[i] = o;
+    }
 }
-
 
 // ---- backward -------------------------------------------------------------------------------------------------
 // y = act(u), u = gamma*xhat + beta, xhat = (x - mean)*invstd.   pass 1: per channel (per image in instance mode)
@@ -166,55 +185,87 @@ __global__ __launch_bounds__(256) void norm_bwd_partial_bf16_kernel(const bf16x8
     }
 }
 
-// group sums [groups*c][3] (and the parameter gradients, summed over the images in instance mode)
-__global__ void norm_bwd_sums_bf16_kernel(const float* __restrict__ part, int c, int slabs_per_group, int groups, float* __restrict__ sums,
-                                          float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ dalpha) {
-    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
-    if (ch >= c) return;
-    double g1 = 0.0, g2 = 0.0, g3 = 0.0;
-    for (int grp = 0; grp < groups; ++grp) {
-        double s1 = 0.0, s2 = 0.0, s3 = 0.0;
-        for (int b = 0; b < slabs_per_group; ++b) {
+// group sums [groups*c][2]; block = (group, 64 channels), 16 row groups sum the slabs, fixed-order combine
+__global__ __launch_bounds__(1024) void norm_bwd_sums_bf16_kernel(const float* __restrict__ part, int c, int slabs_per_group, int groups,
+                                                                   float* __restrict__ sums, float* __restrict__ gsum) {
+    __shared__ double r1[16][64], r2[16][64], r3[16][64];
+    const int cblocks = (c + 63) / 64, grp = blockIdx.x / cblocks, ch = (blockIdx.x - grp * cblocks) * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
+    double s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    if (ch < c)
+        for (int b = g; b < slabs_per_group; b += 16) {
             const float* pp = part + (((long)grp * slabs_per_group + b) * c + ch) * 3;
             s1 += pp[0];
             s2 += pp[1];
             s3 += pp[2];
         }
-        sums[((long)grp * c + ch) * 2] = (float)s1;
-        sums[((long)grp * c + ch) * 2 + 1] = (float)s2;
-        g1 += s1;
-        g2 += s2;
-        g3 += s3;
+    r1[g][threadIdx.x & 63] = s1;
+    r2[g][threadIdx.x & 63] = s2;
+    r3[g][threadIdx.x & 63] = s3;
+    __syncthreads();
+    if (g != 0 || ch >= c) return;
+#pragma unroll
+    for (int i = 1; i < 16; ++i) { s1 += r1[i][threadIdx.x]; s2 += r2[i][threadIdx.x]; s3 += r3[i][threadIdx.x]; }
+    sums[((long)grp * c + ch) * 2] = (float)s1;
+    sums[((long)grp * c + ch) * 2 + 1] = (float)s2;
+    float* gs = gsum + ((long)grp * c + ch) * 3;          // per-group totals for the parameter gradients
+    gs[0] = (float)s1;
+    gs[1] = (float)s2;
+    gs[2] = (float)s3;
+}
+
+// dbeta / dgamma / dalpha [c]: the per-group totals summed over the groups (the images, in instance mode) in order
+__global__ void norm_bwd_params_bf16_kernel(const float* __restrict__ gsum, int c, int groups, float* __restrict__ dgamma,
+                                            float* __restrict__ dbeta, float* __restrict__ dalpha) {
+    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch >= c) return;
+    double g1 = 0.0, g2 = 0.0, g3 = 0.0;
+    for (int grp = 0; grp < groups; ++grp) {
+        const float* gs = gsum + ((long)grp * c + ch) * 3;
+        g1 += gs[0];
+        g2 += gs[1];
+        g3 += gs[2];
     }
     if (dbeta) dbeta[ch] = (float)g1;
     if (dgamma) dgamma[ch] = (float)g2;
     if (dalpha) dalpha[ch] = (float)g3;
 }
 
-__global__ __launch_bounds__(256) void norm_bwd_apply_bf16_kernel(const bf16x8* __restrict__ x, const bf16x8* __restrict__ dy, long total8, int c8,
-                                                                   long pix_per_img, long group_pixels, int per_sample,
+__global__ __launch_bounds__(256) void norm_bwd_apply_bf16_kernel(const bf16x8* __restrict__ x, const bf16x8* __restrict__ dy, int c8,
+                                                                   long pix_per_img, int blocks_per_img, long group_pixels, int per_sample,
                                                                    const float* __restrict__ mean, const float* __restrict__ invstd,
                                                                    const float* __restrict__ gamma, const float* __restrict__ beta, int act,
                                                                    float alpha, const float* __restrict__ prelu, const float* __restrict__ sums,
                                                                    int use_batch_stats, bf16x8* __restrict__ dx) {
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= total8) return;
-    const int ch = (int)(i % c8) * 8;
-    const long img = per_sample ? i / (pix_per_img * c8) : 0;
-    const long sidx = img * c8 * 8 + ch;
+    const int img = blockIdx.x / blocks_per_img, pb = blockIdx.x - img * blocks_per_img;
+    const int ch = threadIdx.x % c8, pl = threadIdx.x / c8, npl = 256 / c8;
+    if (pl >= npl) return;
+    const int pidx = (per_sample ? img * c8 * 8 : 0) + ch * 8;
     const float inv_m = 1.f / (float)group_pixels;
-    const bf16x8 xv = x[i], dv = dy[i];
-    bf16x8 o;
+    float mu[8], is[8], ga[8], be[8], sl[8], m1[8], m2[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        const float is = invstd[sidx + j], ga = gamma ? gamma[ch + j] : 1.f, be = beta ? beta[ch + j] : 0.f;
-        const float xh = ((float)xv[j] - mean[sidx + j]) * is, u = xh * ga + be;
-        const float sl = act == VCG_ACT_PRELU ? prelu[ch + j] : alpha;
-        float dz = (float)dv[j] * act_grad_bf16(u, act, sl);
-        if (use_batch_stats) dz = dz - sums[(sidx + j) * 2] * inv_m - xh * sums[(sidx + j) * 2 + 1] * inv_m;
-        o[j] = (__bf16)(ga * is * dz);
+        mu[j] = mean[pidx + j];
+        is[j] = invstd[pidx + j];
+        ga[j] = gamma ? gamma[ch * 8 + j] : 1.f;
+        be[j] = beta ? beta[ch * 8 + j] : 0.f;
+        sl[j] = act == VCG_ACT_PRELU ? prelu[ch * 8 + j] : (act == VCG_ACT_LRELU ? alpha : 1.f);
+        m1[j] = use_batch_stats ? sums[(pidx + j) * 2] * inv_m : 0.f;
+        m2[j] = use_batch_stats ? sums[(pidx + j) * 2 + 1] * inv_m : 0.f;
     }
-    dx[i] = o;
+    const long p0 = (long)pb * APB, p1 = p0 + APB < pix_per_img ? p0 + APB : pix_per_img;
+    const long base = (long)img * pix_per_img * c8;
+    for (long p = p0 + pl; p < p1; p += npl) {
+        const long i = base + p * c8 + ch;
+        const bf16x8 xv = x[i], dv = dy[i];
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float xh = ((float)xv[j] - mu[j]) * is[j], u = xh * ga[j] + be[j];
+            const float dz = (float)dv[j] * (u > 0.f ? 1.f : sl[j]) - m1[j] - xh * m2[j];
+            o[j] = (__bf16)(ga[j] * is[j] * dz);
+        }
+        dx[i] = o;
+    }
 }
 
 }  // namespace
@@ -238,7 +289,7 @@ int vcg_norm_stats_bf16(const void* x, int n, int c, int hw, int mode, float* me
     const int slabs = (int)((gp + SPB - 1) / SPB);
     stats_partial_bf16_kernel<<<groups * slabs, 256, 2 * 256 * 8 * sizeof(float), stream>>>((const bf16x8*)x, c / 8, gp, slabs, (float*)ws);
     VCG_LAUNCH_CHECK();
-    stats_final_bf16_kernel<<<ceil_div(groups * c, 128), 128, 0, stream>>>((const __bf16*)x, (const float*)ws, c, gp, slabs, groups, mean, var);
+    stats_final_bf16_kernel<<<groups * ceil_div(c, 64), 1024, 0, stream>>>((const __bf16*)x, (const float*)ws, c, gp, slabs, groups, mean, var);
     VCG_LAUNCH_CHECK();
     return VCG_OK;
 }
@@ -247,13 +298,12 @@ int vcg_norm_act_fwd_bf16(const void* x, int n, int c, int hw, const float* scal
                           float alpha, const float* prelu_alpha, const void* residual, void* y, hipStream_t stream) {
     VCG_CHECK_PTR(x); VCG_CHECK_PTR(scale); VCG_CHECK_PTR(shift); VCG_CHECK_PTR(y);
     if (n <= 0 || c <= 0 || hw <= 0) return VCG_E_SHAPE;
-    if (c % 8 != 0) return VCG_E_UNSUPPORTED;
+    if (c % 8 != 0 || c > 256) return VCG_E_UNSUPPORTED;
     if (act == VCG_ACT_PRELU && !prelu_alpha) return VCG_E_NULL;
     if (act == VCG_ACT_TANH) return VCG_E_UNSUPPORTED;
-    const long total8 = (long)n * hw * (c / 8);
-    norm_act_fwd_bf16_kernel<<<(unsigned)((total8 + 255) / 256), 256, 0, stream>>>((const bf16x8*)x, total8, c / 8, hw, scale, shift,
-                                                                                  per_sample, act, alpha, prelu_alpha, (const bf16x8*)residual,
-                                                                                  (bf16x8*)y);
+    const int bpi = ceil_div(hw, APB);
+    norm_act_fwd_bf16_kernel<<<n * bpi, 256, 0, stream>>>((const bf16x8*)x, c / 8, hw, bpi, scale, shift, per_sample, act, alpha, prelu_alpha,
+                                                          (const bf16x8*)residual, (bf16x8*)y);
     VCG_LAUNCH_CHECK();
     return VCG_OK;
 }
@@ -261,7 +311,7 @@ int vcg_norm_act_fwd_bf16(const void* x, int n, int c, int hw, const float* scal
 size_t vcg_norm_act_bwd_bf16_workspace_bytes(int n, int c, int hw, int mode) {
     const long gp = mode == VCG_NORM_INSTANCE ? hw : (long)n * hw;
     const long groups = mode == VCG_NORM_INSTANCE ? n : 1;
-    return (size_t)(groups * ((gp + SPB - 1) / SPB) * c * 3 + groups * c * 2) * sizeof(float);
+    return (size_t)(groups * ((gp + SPB - 1) / SPB) * c * 3 + groups * c * 5) * sizeof(float);
 }
 
 int vcg_norm_act_bwd_bf16(const void* x, const void* dy, int n, int c, int hw, int mode, const float* mean, const float* invstd,
@@ -281,12 +331,16 @@ int vcg_norm_act_bwd_bf16(const void* x, const void* dy, int n, int c, int hw, i
     norm_bwd_partial_bf16_kernel<<<groups * slabs, 256, 3 * 2048 * sizeof(float), stream>>>((const bf16x8*)x, (const bf16x8*)dy, c / 8, gp, slabs, inst,
                                                                                              mean, invstd, gamma, beta, act, act_alpha, prelu_alpha, part);
     VCG_LAUNCH_CHECK();
-    norm_bwd_sums_bf16_kernel<<<ceil_div(c, 64), 64, 0, stream>>>(part, c, slabs, groups, sums, dgamma, dbeta, dprelu_alpha);
+    float* gsum = sums + (size_t)groups * c * 2;
+    norm_bwd_sums_bf16_kernel<<<groups * ceil_div(c, 64), 1024, 0, stream>>>(part, c, slabs, groups, sums, gsum);
     VCG_LAUNCH_CHECK();
-    const long total8 = (long)n * hw * (c / 8);
-    norm_bwd_apply_bf16_kernel<<<(unsigned)((total8 + 255) / 256), 256, 0, stream>>>((const bf16x8*)x, (const bf16x8*)dy, total8, c / 8, hw, gp, inst, mean,
-                                                                                    invstd, gamma, beta, act, act_alpha, prelu_alpha, sums,
-                                                                                    use_batch_stats, (bf16x8*)dx);
+    if (dgamma || dbeta || dprelu_alpha) {
+        norm_bwd_params_bf16_kernel<<<ceil_div(c, 64), 64, 0, stream>>>(gsum, c, groups, dgamma, dbeta, dprelu_alpha);
+        VCG_LAUNCH_CHECK();
+    }
+    const int bpi = ceil_div(hw, APB);
+    norm_bwd_apply_bf16_kernel<<<n * bpi, 256, 0, stream>>>((const bf16x8*)x, (const bf16x8*)dy, c / 8, hw, bpi, gp, inst, mean, invstd, gamma, beta,
+                                                            act, act_alpha, prelu_alpha, sums, use_batch_stats, (bf16x8*)dx);
     VCG_LAUNCH_CHECK();
     return VCG_OK;
 }
