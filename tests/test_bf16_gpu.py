@@ -467,3 +467,26 @@ def test_bf16_trunk_generator_training_forward_and_gradients(rt):
         for k, v in upd.items():                          # moving statistics: momentum 0.99, Bessel-corrected variance
             assert np.max(np.abs(sw[k] - v.detach().numpy())) < 1e-4 * (np.max(np.abs(v.detach().numpy())) + 1e-3), k
     assert out["fp32"][0] < 1e-3 and out["fp32"][1] < 1e-2 and out["fp32"][2] < 1e-4, out["fp32"]
+
+
+def test_bf16_generator_at_c4_frame_size(rt):
+    """bf16 inference at BASELINE.json config C4's frame size (540x960 -> 1080x1920; tiles of 12x32 pixels, 64-column strips and
+    row segments all end raggedly or exactly at the frame edge): a band of the frame against the oracle, which sees the same
+    receptive field away from the band's edges"""
+    from oracle import models as M
+    from upscaler import model as PM
+    h, w, res = 540, 960, 2
+    G = PM.make_upscaler_orig((2 * h, 2 * w, 3), kernel_size=3, upscale_factor=2, res_block_num=res, seed=7)
+    wd = _randomize_bn(G, 3)
+    x = (np.random.RandomState(4).randint(0, 256, (1, h, w, 3)) / 127.5 - 1).astype(np.float32)
+    got = G.to_inference_bf16().predict(x)
+    assert got.shape == (1, 2 * h, 2 * w, 3) and np.isfinite(got).all()
+    for r0 in (0, 254, h - 32):                                  # top edge, interior, bottom edge
+        band = x[:, r0:r0 + 32]
+        with torch.no_grad():
+            ref, _ = M.upscaler_orig_forward(M.to_torch(wd, torch.float64), torch.tensor(band, dtype=torch.float64), False, res, 2)
+        lo = 0 if r0 == 0 else 14                                # rows whose receptive field stays inside the band (or hits the
+        hi = 32 if r0 == h - 32 else 18                          # true frame edge, where both pad with zeros)
+        e = rel_err(got[:, 2 * (r0 + lo):2 * (r0 + hi)], ref[:, 2 * lo:2 * hi].numpy())
+        report("bf16 generator at 540x960->1080x1920, LR rows %d..%d: err=%.2e" % (r0 + lo, r0 + hi, e))
+        assert e < 3e-2
