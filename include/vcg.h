@@ -232,6 +232,15 @@ int vcg_conv9x9_to3_bf16_fwd(const vcg_conv_desc* d, const void* x, const void* 
  * fragments made by vcg_pack_first9x9_bf16 from Keras' (9,9,3,64) fp32 kernel; prelu_alpha may be NULL (no activation). */
 #define VCG_FIRST9X9_WFRAG_BYTES (27 * 64 * 2 * 16)
 int vcg_pack_first9x9_bf16(const void* w, void* out, hipStream_t stream);
+/* the same fragment layout for a 3 -> cout convolution, cout = 64*{1,2,4,8} (cout/64 x VCG_FIRST9X9_WFRAG_BYTES bytes):
+ * dgrad = 0: w is Keras' (9,9,3,cout) kernel, packed for the forward pass; dgrad = 1: w is Keras' (9,9,cout,3) kernel of a
+ * cout -> 3 convolution (final/conv, model.py:290), packed for its data gradient (taps flipped, roles of in/out swapped) */
+int vcg_pack_conv9x9_3ch_bf16(const void* w, int32_t cout, int32_t dgrad, void* out, hipStream_t stream);
+/* data gradient of final/conv on the bf16 path: dy fp32 NCHW [n,3,h,w] -> dx bf16 NHWC [n,h,w,cin]; d describes the FORWARD
+ * convolution (cin = 256, cout = 3).  y_prev (optional): the bf16 NHWC output of the LeakyReLU feeding the convolution
+ * (upsampling_block, model.py:73); dx is then multiplied by its derivative, i.e. it is the gradient in front of the activation. */
+int vcg_conv9x9_to3_bf16_dgrad(const vcg_conv_desc* d, const void* dy, const void* wfrag, const void* y_prev, float lrelu_slope, void* dx,
+                               hipStream_t stream);
 int vcg_conv9x9_from3_bf16_fwd(const vcg_conv_desc* d, const void* x, const void* wfrag, const void* bias, const void* prelu_alpha,
                                void* y, hipStream_t stream);
 

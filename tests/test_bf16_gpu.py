@@ -490,3 +490,32 @@ def test_bf16_generator_at_c4_frame_size(rt):
         e = rel_err(got[:, 2 * (r0 + lo):2 * (r0 + hi)], ref[:, 2 * lo:2 * hi].numpy())
         report("bf16 generator at 540x960->1080x1920, LR rows %d..%d: err=%.2e" % (r0 + lo, r0 + hi, e))
         assert e < 3e-2
+
+
+@pytest.mark.parametrize("n,h,w,mask", [(1, 12, 32, False), (2, 37, 70, True), (1, 5, 9, True)])
+def test_final_conv9x9_bf16_dgrad(rt, n, h, w, mask):
+    """data gradient of final/conv on the bf16 path (the 3-channel 9x9 kernel run with the taps flipped, 4 channel blocks), with
+    the LeakyReLU backward of the tensor in front of it folded into the epilogue"""
+    from oracle import keras_ops as K
+    from upscaler import _lib as L
+    g = torch.Generator().manual_seed(n * 100 + h + w)
+    wk = torch.randn(9, 9, 256, 3, generator=g) * 0.02
+    dy = torch.randn(n, 3, h, w, generator=g)
+    yprev = torch.randn(n, 256, h, w, generator=g)
+    x = torch.zeros(n, 256, h, w, dtype=torch.float64, requires_grad=True)
+    (K.conv2d(x, _bf16_round(wk), None, 1, "same") * _bf16_round(dy)).sum().backward()
+    ref = x.grad
+    if mask:
+        ref = ref * torch.where(_bf16_round(yprev) > 0, 1.0, 0.2)
+    wf = torch.empty(4 * L.FIRST9X9_WFRAG_BYTES, dtype=torch.uint8, device=rt.device)
+    wd = wk.to(rt.device)
+    L.check(rt.lib.vcg_pack_conv9x9_3ch_bf16(wd.data_ptr(), 256, 1, wf.data_ptr(), rt.stream), "pack dgrad")
+    dyd = dy.to(rt.device)
+    yp = _to_nhwc_bf16(rt, yprev.to(rt.device))
+    dx = torch.empty(n, h, w, 256, dtype=torch.bfloat16, device=rt.device)
+    d = L.ConvDesc(n, 256, h, w, 3, h, w, 9, 9, 1, 4, 4)
+    L.check(rt.lib.vcg_conv9x9_to3_bf16_dgrad(ctypes.byref(d), dyd.data_ptr(), wf.data_ptr(), yp.data_ptr() if mask else None, 0.2, dx.data_ptr(),
+                                              rt.stream), "vcg_conv9x9_to3_bf16_dgrad")
+    e = rel_err(_to_nchw_f32(rt, dx), ref)
+    report("bf16 final conv dgrad 3->256 n=%d %dx%d mask=%s err=%.2e" % (n, h, w, mask, e))
+    assert e < TOL_BF16

@@ -349,10 +349,12 @@ constexpr int I_NPRE = (I_NPIX + NLW * 64 - 1) / (NLW * 64);      // 7 pixels pe
 struct I9Params {
     const float* x;          // fp32 NCHW [n][3][h][w]
     const uint4* w;          // packed fragments (vcg_pack_first9x9_bf16)
-    const float* bias;       // [64] or null
-    const float* alpha;      // PReLU slopes [64] or null (none)
-    __bf16* y;               // bf16 NHWC [n][h][w][64]
-    int n, h, w_, tiles_x, tiles_y, total;
+    const float* bias;       // [cout] or null
+    const float* alpha;      // PReLU slopes [cout] or null (none)
+    __bf16* y;               // bf16 NHWC [n][h][w][cout]
+    const __bf16* mask;      // optional bf16 NHWC [n][h][w][cout]: y *= (mask > 0 ? 1 : mask_slope)  (data gradient in front of a LeakyReLU)
+    float mask_slope;
+    int n, h, w_, cout, tiles_x, tiles_y, total;        // cout = 64 * nblk; workgroup b serves channel block b % nblk
 };
 
 __global__ __launch_bounds__(NT, 1) void conv9x9_c3to64_bf16_kernel(I9Params p) {
@@ -362,11 +364,12 @@ __global__ __launch_bounds__(NT, 1) void conv9x9_c3to64_bf16_kernel(I9Params p) 
     float* prm = (float*)(smem + I_WB + I_XB);       // bias[64], slope[64]
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, hh = lane >> 5;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nblk = p.cout >> 6, cb = blockIdx.x % nblk, wg0 = blockIdx.x / nblk, nwg = gridDim.x / nblk;
 
-    for (int c = tid; c < I_WB / 16; c += NT) ((uint4*)wl)[c] = p.w[c];
+    for (int c = tid; c < I_WB / 16; c += NT) ((uint4*)wl)[c] = p.w[(long)cb * (I_WB / 16) + c];
     if (tid < 64) {
-        prm[tid] = p.bias ? p.bias[tid] : 0.f;
-        prm[64 + tid] = p.alpha ? p.alpha[tid] : 1.f;
+        prm[tid] = p.bias ? p.bias[cb * 64 + tid] : 0.f;
+        prm[64 + tid] = p.alpha ? p.alpha[cb * 64 + tid] : 1.f;
     }
     const long plane = (long)p.h * p.w_;
 
@@ -403,12 +406,12 @@ __global__ __launch_bounds__(NT, 1) void conv9x9_c3to64_bf16_kernel(I9Params p) 
                 *(bf16x4*)(xl + pix * 8) = v;
             }
         };
-        int tile = blockIdx.x;
-        fetch(tile);
+        int tile = wg0;
+        if (tile < p.total) fetch(tile);
         stash();
         lds_barrier();
-        for (; tile < p.total; tile += gridDim.x) {
-            const int next = tile + gridDim.x;
+        for (; tile < p.total; tile += nwg) {
+            const int next = tile + nwg;
             if (next < p.total) fetch(next);
             lds_barrier();
             if (next < p.total) stash();
@@ -421,7 +424,7 @@ __global__ __launch_bounds__(NT, 1) void conv9x9_c3to64_bf16_kernel(I9Params p) 
     const unsigned char* xb = xl + (wv * 2) * I_ROWB + (r + 2 * hh) * 8;
     lds_barrier();
 
-    for (int tile = blockIdx.x; tile < p.total; tile += gridDim.x) {
+    for (int tile = wg0; tile < p.total; tile += nwg) {
         const int txi = tile % p.tiles_x, t2 = tile / p.tiles_x, tyi = t2 % p.tiles_y, img = t2 / p.tiles_y;
         const int gx = txi * TC + r, gy0 = tyi * TR + wv * 2;
         const bool okx = gx < p.w_;
@@ -480,30 +483,42 @@ __global__ __launch_bounds__(NT, 1) void conv9x9_c3to64_bf16_kernel(I9Params p) 
                         v[j] = lo;
                         v[4 + j] = hi;
                     }
+                    const int gy = gy0 + pt;
+                    const bool ok = gy < p.h && okx;
+                    const long o = ((long)(img * p.h + min(gy, p.h - 1)) * p.w_ + min(gx, p.w_ - 1)) * p.cout + cb * 64 + co;
+                    bf16x8 mk;
+                    if (p.mask) mk = *(const bf16x8*)(p.mask + o);
                     bf16x8 ov;
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
-                        const float u = v[j] + sh[j];
-                        ov[j] = (__bf16)(u >= 0.f ? u : u * al[j]);
+                        float u = v[j] + sh[j];
+                        u = u >= 0.f ? u : u * al[j];
+                        if (p.mask) u = (float)mk[j] > 0.f ? u : u * p.mask_slope;
+                        ov[j] = (__bf16)u;
                     }
-                    const int gy = gy0 + pt;
-                    if (gy < p.h && okx) *(bf16x8*)(p.y + ((long)(img * p.h + gy) * p.w_ + gx) * 64 + co) = ov;
+                    if (ok) *(bf16x8*)(p.y + o) = ov;
                 }
             }
         lds_barrier();
     }
 }
 
-__global__ void pack_first9x9_kernel(const float* __restrict__ w, uint4* __restrict__ out) {
-    // w: Keras (9,9,3,64) -> out[k-step = ky*3+j][co][half] = 8 bf16: (kx = 4j+2*half, RGB0), (kx+1, RGB0)
+__global__ void pack_first9x9_kernel(const float* __restrict__ w, uint4* __restrict__ out, int cout, int dgrad) {
+    // out[channel block][k-step = ky*3+j][co in block][half] = 8 bf16: (kx = 4j+2*half, RGB0), (kx+1, RGB0)
+    //   dgrad == 0: w is Keras (9,9,3,cout), the forward kernel of a 3 -> cout convolution
+    //   dgrad == 1: w is Keras (9,9,cout,3), the kernel of a cout -> 3 convolution; packed for its DATA GRADIENT
+    //               (a 3 -> cout convolution with the taps flipped):  W'[ky][kx][c][m] = w[8-ky][8-kx][m][c]
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= 27 * 64 * 2) return;
-    const int h = idx & 1, co = (idx >> 1) & 63, ks = idx >> 7, ky = ks / 3, j = ks - 3 * ky;
+    if (idx >= (cout >> 6) * 27 * 64 * 2) return;
+    const int h = idx & 1, co = (idx >> 1) & 63, ks = (idx >> 7) % 27, cb = idx / (27 * 128), ky = ks / 3, j = ks - 3 * ky;
+    const int m = cb * 64 + co;
     bf16x8 v;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         const int kx = 4 * j + 2 * h + (e >> 2), c = e & 3;
-        v[e] = (__bf16)((kx < 9 && c < 3) ? w[((ky * 9 + kx) * 3 + c) * 64 + co] : 0.f);
+        float x = 0.f;
+        if (kx < 9 && c < 3) x = dgrad ? w[(((8 - ky) * 9 + (8 - kx)) * cout + m) * 3 + c] : w[((ky * 9 + kx) * 3 + c) * cout + m];
+        v[e] = (__bf16)x;
     }
     out[idx] = __builtin_bit_cast(uint4, v);
 }
@@ -1040,9 +1055,48 @@ int vcg_conv9x9_to3_bf16_fwd(const vcg_conv_desc* d, const void* x, const void* 
 }
 
 int vcg_pack_first9x9_bf16(const void* w, void* out, hipStream_t stream) {
+    return vcg_pack_conv9x9_3ch_bf16(w, 64, 0, out, stream);
+}
+
+int vcg_pack_conv9x9_3ch_bf16(const void* w, int32_t cout, int32_t dgrad, void* out, hipStream_t stream) {
     VCG_CHECK_PTR(w);
     VCG_CHECK_PTR(out);
-    pack_first9x9_kernel<<<(27 * 64 * 2 + 255) / 256, 256, 0, stream>>>((const float*)w, (uint4*)out);
+    if (cout <= 0 || cout % 64 != 0) return VCG_E_SHAPE;
+    const int total = (cout >> 6) * 27 * 64 * 2;
+    pack_first9x9_kernel<<<(total + 255) / 256, 256, 0, stream>>>((const float*)w, (uint4*)out, cout, dgrad);
+    VCG_LAUNCH_CHECK();
+    return VCG_OK;
+}
+
+static int launch_conv9x9_3ch(const vcg_conv_desc* d, int cout, const void* x, const void* wfrag, const void* bias, const void* prelu_alpha,
+                              const void* mask, float mask_slope, void* y, hipStream_t stream) {
+    const int nblk = cout / 64;
+    if (cout % 64 != 0 || nblk < 1 || nblk > 8 || (nblk & (nblk - 1))) return VCG_E_UNSUPPORTED;
+    I9Params p;
+    p.x = (const float*)x;
+    p.w = (const uint4*)wfrag;
+    p.bias = (const float*)bias;
+    p.alpha = (const float*)prelu_alpha;
+    p.y = (__bf16*)y;
+    p.mask = (const __bf16*)mask;
+    p.mask_slope = mask_slope;
+    p.n = d->n;
+    p.h = d->h;
+    p.w_ = d->w;
+    p.cout = cout;
+    p.tiles_x = ceil_div(d->w, TC);
+    p.tiles_y = ceil_div(d->h, TR);
+    p.total = p.n * p.tiles_x * p.tiles_y;
+    const int lds = I_WB + I_XB + 512;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)conv9x9_c3to64_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    int per = 512 / nblk;                                   // 62 KiB of LDS: two workgroups per CU
+    if (per > p.total) per = p.total;
+    conv9x9_c3to64_bf16_kernel<<<per * nblk, NT, lds, stream>>>(p);
     VCG_LAUNCH_CHECK();
     return VCG_OK;
 }
@@ -1054,30 +1108,19 @@ int vcg_conv9x9_from3_bf16_fwd(const vcg_conv_desc* d, const void* x, const void
     VCG_CHECK_PTR(wfrag);
     VCG_CHECK_PTR(y);
     if (d->n <= 0 || d->h <= 0 || d->w <= 0 || d->oh != d->h || d->ow != d->w) return VCG_E_SHAPE;
-    if (d->cin != 3 || d->cout != 64 || d->kh != 9 || d->kw != 9 || d->stride != 1 || d->pad_top != 4 || d->pad_left != 4) return VCG_E_UNSUPPORTED;
-    I9Params p;
-    p.x = (const float*)x;
-    p.w = (const uint4*)wfrag;
-    p.bias = (const float*)bias;
-    p.alpha = (const float*)prelu_alpha;
-    p.y = (__bf16*)y;
-    p.n = d->n;
-    p.h = d->h;
-    p.w_ = d->w;
-    p.tiles_x = ceil_div(d->w, TC);
-    p.tiles_y = ceil_div(d->h, TR);
-    p.total = p.n * p.tiles_x * p.tiles_y;
-    const int lds = I_WB + I_XB + 512;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv9x9_c3to64_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
-    const int grid = p.total < 512 ? p.total : 512;        // 62 KiB of LDS: two workgroups per CU
-    conv9x9_c3to64_bf16_kernel<<<grid, NT, lds, stream>>>(p);
-    VCG_LAUNCH_CHECK();
-    return VCG_OK;
+    if (d->cin != 3 || d->kh != 9 || d->kw != 9 || d->stride != 1 || d->pad_top != 4 || d->pad_left != 4) return VCG_E_UNSUPPORTED;
+    return launch_conv9x9_3ch(d, d->cout, x, wfrag, bias, prelu_alpha, nullptr, 0.f, y, stream);
+}
+
+int vcg_conv9x9_to3_bf16_dgrad(const vcg_conv_desc* d, const void* dy, const void* wfrag, const void* y_prev, float lrelu_slope, void* dx,
+                               hipStream_t stream) {
+    VCG_CHECK_PTR(d);
+    VCG_CHECK_PTR(dy);
+    VCG_CHECK_PTR(wfrag);
+    VCG_CHECK_PTR(dx);
+    if (d->n <= 0 || d->h <= 0 || d->w <= 0 || d->oh != d->h || d->ow != d->w) return VCG_E_SHAPE;
+    if (d->cout != 3 || d->kh != 9 || d->kw != 9 || d->stride != 1 || d->pad_top != 4 || d->pad_left != 4) return VCG_E_UNSUPPORTED;
+    return launch_conv9x9_3ch(d, d->cin, dy, wfrag, nullptr, nullptr, y_prev, lrelu_slope, dx, stream);
 }
 
 }  // extern "C"
