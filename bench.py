@@ -100,7 +100,7 @@ def main():
     ap.add_argument("--content", default="mse", choices=["mse", "vgg_mse"],
                     help="content loss: pixel MSE (C2 as SURVEY 8d defines it) or the reference's default VGG_MSE_LOSS form with "
                          "seeded random VGG19 weights (ImageNet weights cannot be fetched offline)")
-    ap.add_argument("--trunk-dtype", default="fp32", choices=["fp32", "bf16"],
+    ap.add_argument("--trunk-dtype", default="fp32", choices=["fp32", "bf16", "bf16+tail"],
                     help="bf16: the generator's residual trunk trains on bf16 activations (mixed precision; NOT config C2, reported as such)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying one hipGraph per step")
@@ -220,7 +220,7 @@ def main():
             "metric": METRIC, "value": round(frames / dt, 3), "unit": "frames/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if args.trunk_dtype == "fp32" else "bf16 trunk activations / f32 elsewhere (mixed; not C2)", "data": "synthetic",
+            "dtype": "f32" if args.trunk_dtype == "fp32" else "generator %s activations bf16 / f32 elsewhere (mixed; not C2)" % ("trunk" if args.trunk_dtype == "bf16" else "trunk + up-sampling + final conv"), "data": "synthetic",
             "config": {"workload": "C2: make_upscaler_orig((%d,%d,3),k=3,x2,res=%d) + %s, batch %d/GPU, "
                                    "gan2 wiring, Wasserstein + %s, faithful 3-call step incl. predict pass"
                                    % (2 * h, 2 * h, args.res_blocks, "PatchGAN-70" if args.disc == "patchgan" else "simple_512",

@@ -98,11 +98,12 @@ def init_upscaler_orig(output_image_shape, kernel_size=5, filters=64, upscale_fa
     return w
 
 
-def upscaler_orig_forward(w, x_nhwc, training, res_block_num, upscale_factor, taps=None, norm="batch", trunk_bf16=False):
+def upscaler_orig_forward(w, x_nhwc, training, res_block_num, upscale_factor, taps=None, norm="batch", trunk_bf16=False, tail_bf16=False):
     """x_nhwc: [N,h,w,3] -> ([N,h*f,w*f,3], bn_updates).  ``training`` selects batch vs moving BN
     statistics (Keras learning phase: predict=0, train_on_batch=1).  ``taps`` (optional dict)
     receives named NCHW intermediates for kernel-level parity tests.  ``trunk_bf16`` marks the tensors the
-    product's ``trunk_dtype='bf16'`` mode stores in bf16 (values and gradients; keras_ops.bf16_*)."""
+    product's ``trunk_dtype='bf16'`` mode stores in bf16 (values and gradients; keras_ops.bf16_*); ``tail_bf16`` adds those of
+    ``'bf16+tail'`` (up-sampling block and final/conv)."""
     upd = OrderedDict()
     st = K.bf16_store if trunk_bf16 else (lambda v: v)
     rf = K.bf16_round_fwd if trunk_bf16 else (lambda v: v)
@@ -144,11 +145,14 @@ def upscaler_orig_forward(w, x_nhwc, training, res_block_num, upscale_factor, ta
     m = tconv(m, "prefinal/conv2d")
     m = rg(bn(m, "prefinal/batch_norm"))
     m = tap("prefinal/tanh", rf(skip + m))                        # Add misnamed in model.py:285
+    trf = K.bf16_round_fwd if tail_bf16 else (lambda v: v)
+    trg = K.bf16_round_grad if tail_bf16 else (lambda v: v)
     for i in range(int(math.log(upscale_factor, 2))):
         n = "upscaling/%d/block" % i
-        m = K.conv2d_transpose_same(m, w[n + "/conv_transp/kernel"], w[n + "/conv_transp/bias"], 2)
-        m = tap(n + "/leaky_relu", K.leaky_relu(m, 0.2))
-    m = tap("final/conv", conv(m, "final/conv"))
+        m = K.conv2d_transpose_same(m, trf(w[n + "/conv_transp/kernel"]), w[n + "/conv_transp/bias"], 2)
+        m = tap(n + "/leaky_relu", trf(K.leaky_relu(trg(m), 0.2)))      # output stored in bf16; the gradient IN FRONT of the
+        #                                                                 activation is what the product stores in bf16
+    m = tap("final/conv", K.conv2d(m, trf(w["final/conv/kernel"]), w["final/conv/bias"], 1, "same"))
     m = torch.tanh(m)
     return m.permute(0, 2, 3, 1), upd
 

@@ -406,7 +406,8 @@ def test_norm_bwd_bf16(rt, mode, n, c, h, w, act):
     assert all(v < 2e-4 for k, v in errs.items() if k != "dx")
 
 
-def test_bf16_trunk_generator_training_forward_and_gradients(rt):
+@pytest.mark.parametrize("mode", ["bf16", "bf16+tail"])
+def test_bf16_trunk_generator_training_forward_and_gradients(rt, mode):
     """make_upscaler_orig(..., trunk_dtype='bf16'): the residual trunk trains on bf16 activations (conv fwd / dgrad /
     wgrad, norm fwd / bwd in bf16_*.hip) with fp32 master weights.  Training-mode forward, loss and every gradient tensor
     against the fp64 oracle evaluated WITH THE SAME STORAGE ROUNDINGS (oracle.keras_ops.bf16_store at the tensors the
@@ -416,7 +417,7 @@ def test_bf16_trunk_generator_training_forward_and_gradients(rt):
     from oracle import models as M
     from upscaler import model as PM, _engine as E
     res, n, h, w = 2, 4, 32, 32
-    Gb = PM.make_upscaler_orig((2 * h, 2 * w, 3), kernel_size=3, upscale_factor=2, res_block_num=res, seed=7, trunk_dtype="bf16")
+    Gb = PM.make_upscaler_orig((2 * h, 2 * w, 3), kernel_size=3, upscale_factor=2, res_block_num=res, seed=7, trunk_dtype=mode)
     Gf = PM.make_upscaler_orig((2 * h, 2 * w, 3), kernel_size=3, upscale_factor=2, res_block_num=res, seed=7)
     wd = _randomize_bn(Gb, 5)
     Gf.set_weights_dict(wd)
@@ -425,7 +426,8 @@ def test_bf16_trunk_generator_training_forward_and_gradients(rt):
 
     def oracle(trunk_bf16, dt=torch.float64):
         leaf = M.to_torch(wd, dt, requires_grad=True)
-        yr, upd = M.upscaler_orig_forward(leaf, torch.tensor(x, dtype=dt), True, res, 2, trunk_bf16=trunk_bf16)
+        yr, upd = M.upscaler_orig_forward(leaf, torch.tensor(x, dtype=dt), True, res, 2, trunk_bf16=trunk_bf16,
+                                          tail_bf16=trunk_bf16 and mode == "bf16+tail")
         loss = ((yr - torch.tensor(t, dtype=dt)) ** 2).mean()
         names = [k for k, v in leaf.items() if v.requires_grad]
         return yr.detach().double(), float(loss.detach()), dict(zip(names, [g.double() for g in torch.autograd.grad(loss, [leaf[k] for k in names])])), upd
@@ -460,7 +462,7 @@ def test_bf16_trunk_generator_training_forward_and_gradients(rt):
             e32_g = max(l2(g32[k], b, 1e-4 * gmax * b.numel() ** 0.5) for k, b in gref.items())
             report("    oracle fp32-with-bf16-storage vs oracle fp64-with-bf16-storage: output %.2e, worst gradient tensor %.2e" % (e32_y, e32_g))
             assert e_y < max(1e-3, 2.5 * e32_y) and worst < max(1e-2, 2.5 * e32_g) and out[tag][2] < 1e-4, (out[tag], e32_y, e32_g)
-        report("generator training pass (%s) vs oracle with the same storage: output err (rel L2)=%.2e  worst gradient tensor (rel L2)=%.2e  loss err=%.1e"
+        report("generator training pass [" + mode + "] (%s) vs oracle with the same storage: output err (rel L2)=%.2e  worst gradient tensor (rel L2)=%.2e  loss err=%.1e"
                "   [vs un-rounded fp64 oracle: output %.2e, gradients %.2e]"
                % ((tag,) + out[tag] + (l2(yd, ref["fp32"][0]), worst_plain)))
         sw = G.get_weights_dict()

@@ -586,6 +586,140 @@ class Conv3x3Bf16(Layer):
         return dx
 
 
+class ConvT3x3Bf16(ConvT2D):
+    """upsampling_block (model.py:70-75) with bf16 activations: Conv2DTranspose(3, strides 2) 64 -> 64m + bias + LeakyReLU forward on
+    vcg_conv_transpose2d_bf16_fwd (bf16 NHWC in and out).  Backward takes the gradient in front of the activation (the bf16 data
+    gradient of final/conv applies the LeakyReLU derivative itself) and, until the bf16 transposed-convolution gradients exist,
+    runs the fp32 kernels on fp32 NCHW copies of the bf16 operands (exact conversions) with the bf16-rounded kernel -- the weights
+    the forward pass used."""
+
+    def __init__(self, name, cin, cout, k, act=L.ACT_NONE, alpha=0.0):
+        if k != 3 or cin != 64 or cout % 64:
+            raise NotImplementedError("the bf16 transposed convolution is instantiated for 3x3, 64 -> 64m channels")
+        super().__init__(name, cin, cout, k, act, alpha)
+        self._wp = self._wr = None
+        self._pvalid = False
+
+    def refresh(self):
+        super().refresh()
+        self._pvalid = False
+
+    def _packed(self):
+        rt = self.rt
+        if self._wp is None:
+            self._wp = torch.empty(9, self.cout, self.cin, dtype=torch.bfloat16, device=rt.device)
+        if not self._pvalid:
+            w = self.ps[self.name + "/kernel"]
+            L.check(rt.lib.vcg_pack_conv_kernel_bf16(w.data_ptr(), 9, self.cout, self.cin, 0, 0, self._wp.data_ptr(), rt.stream), "pack convT")
+            self._wr = w.to(torch.bfloat16).to(torch.float32)        # the kernel as the forward pass saw it (a cast, fp32 layout)
+            self._pvalid = True
+        return self._wp, self._wr
+
+    def forward(self, x, tag=None):
+        rt = self.rt
+        n, h, w, _ = x.shape
+        wp, _ = self._packed()
+        y = torch.empty(n, 2 * h, 2 * w, self.cout, dtype=torch.bfloat16, device=rt.device)
+        d = self.desc(n, h, w)
+        ep = L.EpilogueBf16(None, self.ps[self.name + "/bias"].data_ptr(), self.act, float(self.alpha), None, None)
+        with Timed(rt, tag):
+            L.check(rt.lib.vcg_conv_transpose2d_bf16_fwd(ctypes.byref(d), x.data_ptr(), wp.data_ptr(), y.data_ptr(), ctypes.byref(ep), rt.stream),
+                    "vcg_conv_transpose2d_bf16_fwd[%s]" % self.name)
+        return y, (x, y, d)
+
+    def backward(self, ctx, dz, need_dx=True, param_grads=True, which=0, tag=None):
+        """dz: bf16 NHWC gradient in front of the LeakyReLU.  Returns dx as fp32 NCHW."""
+        rt = self.rt
+        x, _, d = ctx
+        x32, dz32 = from_bf16_nhwc(rt, x), from_bf16_nhwc(rt, dz)
+        _, wr = self._packed()
+        if param_grads:
+            ws, wsn = rt.workspace(rt.lib.vcg_conv_transpose2d_wgrad_workspace_bytes(ctypes.byref(d)))
+            with Timed(rt, tag and tag + "_wgrad"):
+                L.check(rt.lib.vcg_conv_transpose2d_wgrad(ctypes.byref(d), x32.data_ptr(), dz32.data_ptr(), self.ps.grad(self.name + "/kernel", which).data_ptr(),
+                                                          self.ps.grad(self.name + "/bias", which).data_ptr(), ws, wsn, rt.stream),
+                        "vcg_conv_transpose2d_wgrad[%s]" % self.name)
+        if not need_dx:
+            return None
+        dx = rt.empty(d.n, self.cin, d.h, d.w)
+        with Timed(rt, tag and tag + "_dgrad"):
+            L.check(rt.lib.vcg_conv_transpose2d_dgrad(ctypes.byref(d), dz32.data_ptr(), wr.data_ptr(), dx.data_ptr(), None, rt.stream),
+                    "vcg_conv_transpose2d_dgrad[%s]" % self.name)
+        return dx
+
+
+class FinalConv9x9Bf16(Conv2D):
+    """final/conv (model.py:290-291): Conv2D(3, 9) + tanh on a bf16 NHWC input with 256 channels, fp32 NCHW output.  Forward on
+    vcg_conv9x9_to3_bf16_fwd; data gradient on vcg_conv9x9_to3_bf16_dgrad, which also applies the derivative of the LeakyReLU that
+    produced the input (so the result is the gradient in front of that activation); the weight gradient still runs the fp32 kernel
+    on an fp32 NCHW copy of the input (exact conversion)."""
+
+    def __init__(self, name, cin, cout, k, act=L.ACT_TANH):
+        if cin != 256 or cout != 3 or k != 9:
+            raise NotImplementedError("the bf16 final convolution is instantiated for 9x9, 256 -> 3 channels")
+        super().__init__(name, cin, cout, k, 1, "same", act)
+        self._wf = self._wd = None
+        self._pvalid = False
+
+    def refresh(self):
+        super().refresh()
+        self._pvalid = False
+
+    def _packed(self):
+        rt = self.rt
+        if self._wf is None:
+            self._wf = torch.empty(L.FINAL9X9_WFRAG_BYTES, dtype=torch.uint8, device=rt.device)
+            self._wd = torch.empty(4 * L.FIRST9X9_WFRAG_BYTES, dtype=torch.uint8, device=rt.device)
+        if not self._pvalid:
+            w = self.ps[self.name + "/kernel"].data_ptr()
+            L.check(rt.lib.vcg_pack_final9x9_bf16(w, self._wf.data_ptr(), rt.stream), "vcg_pack_final9x9_bf16")
+            L.check(rt.lib.vcg_pack_conv9x9_3ch_bf16(w, 256, 1, self._wd.data_ptr(), rt.stream), "vcg_pack_conv9x9_3ch_bf16")
+            self._pvalid = True
+        return self._wf, self._wd
+
+    def forward(self, x, residual=None, tag=None):
+        rt = self.rt
+        n, h, w, _ = x.shape
+        wf, _ = self._packed()
+        d = self.desc(n, h, w)
+        y = rt.empty(n, 3, h, w)
+        with Timed(rt, tag):
+            L.check(rt.lib.vcg_conv9x9_to3_bf16_fwd(ctypes.byref(d), x.data_ptr(), wf.data_ptr(), self.ps[self.name + "/bias"].data_ptr(),
+                                                    1 if self.act == L.ACT_TANH else 0, y.data_ptr(), rt.stream), "vcg_conv9x9_to3_bf16_fwd")
+        return y, (x, y, d)
+
+    def backward(self, ctx, dy, need_dx=True, param_grads=True, which=0, tag=None, input_lrelu_slope=None):
+        """returns dx as bf16 NHWC; with input_lrelu_slope it is already the gradient in front of the LeakyReLU whose output x is"""
+        rt = self.rt
+        x, y, d = ctx
+        n = d.n
+        db_done = False
+        if self.act != L.ACT_NONE:
+            dz = rt.empty(*dy.shape)
+            db = self.ps.grad(self.name + "/bias", which).data_ptr() if param_grads else None
+            ws, wsn = rt.workspace(rt.lib.vcg_act_bwd_workspace_bytes(n, 3, d.oh * d.ow))
+            L.check(rt.lib.vcg_act_bwd(y.data_ptr(), dy.data_ptr(), n, 3, d.oh * d.ow, self.act, 0.0, None, dz.data_ptr(), None, db, ws, wsn,
+                                       rt.stream), "vcg_act_bwd[%s]" % self.name)
+            dy, db_done = dz, True
+        if param_grads:
+            x32 = from_bf16_nhwc(rt, x)
+            ws, wsn = rt.workspace(rt.lib.vcg_conv2d_wgrad_workspace_bytes(ctypes.byref(d)))
+            with Timed(rt, tag and tag + "_wgrad"):
+                L.check(rt.lib.vcg_conv2d_wgrad(ctypes.byref(d), x32.data_ptr(), dy.data_ptr(), self.ps.grad(self.name + "/kernel", which).data_ptr(),
+                                                None if db_done else self.ps.grad(self.name + "/bias", which).data_ptr(), ws, wsn, rt.stream),
+                        "vcg_conv2d_wgrad[%s]" % self.name)
+            del x32
+        if not need_dx:
+            return None
+        _, wd = self._packed()
+        dx = torch.empty_like(x)
+        with Timed(rt, tag and tag + "_dgrad"):
+            L.check(rt.lib.vcg_conv9x9_to3_bf16_dgrad(ctypes.byref(d), dy.data_ptr(), wd.data_ptr(),
+                                                      x.data_ptr() if input_lrelu_slope is not None else None,
+                                                      float(input_lrelu_slope or 0.0), dx.data_ptr(), rt.stream), "vcg_conv9x9_to3_bf16_dgrad")
+        return dx
+
+
 class NormActBf16(Layer):
     """NormAct on bf16 NHWC (same parameters / names): statistics, affine and activation arithmetic in fp32."""
 

@@ -404,8 +404,15 @@ class UpscalerOrig(Model):
     def __init__(self, output_image_shape, kernel_size, filters, upscale_factor, res_block_num, norm, seed, trunk_dtype="fp32"):
         f = upscale_factor
         super().__init__("upscaler_orig", (output_image_shape[0] // f, output_image_shape[1] // f, output_image_shape[2]), seed)
-        if trunk_dtype not in ("fp32", "bf16"):
+        if trunk_dtype not in ("fp32", "bf16", "bf16+tail"):
             raise ValueError(trunk_dtype)
+        # 'bf16+tail': also the up-sampling block and final/conv on bf16 activations (forward entirely, backward where the
+        # bf16 gradient kernels exist: _engine.ConvT3x3Bf16 / FinalConv9x9Bf16); needs the x2 topology with 64 -> 256 -> 3
+        self.tail_bf16 = trunk_dtype == "bf16+tail"
+        if self.tail_bf16:
+            trunk_dtype = "bf16"
+            if upscale_factor != 2:
+                raise NotImplementedError("the bf16 tail is instantiated for upscale_factor=2")
         if trunk_dtype == "bf16" and (kernel_size != 3 or filters != 64):
             raise NotImplementedError("the bf16 trunk is instantiated for kernel_size=3, filters=64")
         self.trunk_dtype = trunk_dtype
@@ -431,10 +438,11 @@ class UpscalerOrig(Model):
         self.n_pre = self._add(normact("prefinal/batch_norm", 64, nrm))
         self.ups = []
         cin = 64
+        upc = E.ConvT3x3Bf16 if self.tail_bf16 else E.ConvT2D
         for i in range(self.upscale_times):
-            self.ups.append(self._add(E.ConvT2D("upscaling/%d/block/conv_transp" % i, cin, 256, k, L.ACT_LRELU, 0.2)))
+            self.ups.append(self._add(upc("upscaling/%d/block/conv_transp" % i, cin, 256, k, L.ACT_LRELU, 0.2)))
             cin = 256                                                                 # 256: model.py:288
-        self.c_fin = self._add(E.Conv2D("final/conv", cin, 3, 9, act=L.ACT_TANH))
+        self.c_fin = self._add(E.FinalConv9x9Bf16("final/conv", cin, 3, 9) if self.tail_bf16 else E.Conv2D("final/conv", cin, 3, 9, act=L.ACT_TANH))
         self._finish()
 
     def _out_shape(self, s):
@@ -460,7 +468,7 @@ class UpscalerOrig(Model):
             h, a = n2.forward(h, training, residual=gen); tape.append(a)
         h, a = self.c_pre.forward(h, tag="trunk_conv"); tape.append(a)
         h, a = self.n_pre.forward(h, training, residual=skip); tape.append(a)
-        if self.trunk_dtype == "bf16":
+        if self.trunk_dtype == "bf16" and not self.tail_bf16:
             h = E.from_bf16_nhwc(self.rt, h)
         for u in self.ups:
             h, a = u.forward(h, tag="convt"); tape.append(a)
@@ -471,9 +479,14 @@ class UpscalerOrig(Model):
         """gradient of all trainables into grads[which]; dy = dL/d(output) NCHW."""
         rt = self.rt
         tape = list(tape)
-        d = self.c_fin.backward(tape.pop(), dy, True, True, which, tag="final_conv")
-        for u in reversed(self.ups):
-            d = u.backward(tape.pop(), d, True, True, which, tag="convt")
+        if self.tail_bf16:
+            # final/conv's bf16 data gradient applies the up-sampling block's LeakyReLU derivative; the block returns fp32 NCHW
+            d = self.c_fin.backward(tape.pop(), dy, True, True, which, tag="final_conv", input_lrelu_slope=self.ups[-1].alpha)
+            d = self.ups[-1].backward(tape.pop(), d, True, True, which, tag="convt")
+        else:
+            d = self.c_fin.backward(tape.pop(), dy, True, True, which, tag="final_conv")
+            for u in reversed(self.ups):
+                d = u.backward(tape.pop(), d, True, True, which, tag="convt")
         # s = skip + BN(conv(h)):  d flows to both
         dskip = d
         if self.trunk_dtype == "bf16":
