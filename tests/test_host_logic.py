@@ -153,3 +153,45 @@ def test_product_sources_do_not_reference_the_oracle():
             if f.endswith((".py", ".hip", ".hpp")):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle", txt, flags=re.M), f
+
+
+def test_c_abi_argument_validation_without_a_gpu():
+    """Error convention of the C ABI (include/vcg.h: 0 ok, <0 VCG_E_*, >0 hipError_t): argument checks come before any device
+    work, so they can be exercised on a box without a GPU."""
+    import ctypes
+    from upscaler import _lib as L
+    lib = L.load()
+    E_NULL, E_SHAPE, E_UNSUPPORTED, E_WORKSPACE = -1, -2, -3, -4
+    d = L.ConvDesc(1, 64, 8, 8, 64, 8, 8, 3, 3, 1, 1, 1)
+    one = ctypes.c_void_p(16)                              # any non-null address: never dereferenced by the checks below
+    # required pointers
+    assert lib.vcg_conv2d_fwd(ctypes.byref(d), None, one, one, None, None) == E_NULL
+    assert lib.vcg_conv2d_bf16_fwd(ctypes.byref(d), one, None, one, None, None) == E_NULL
+    assert lib.vcg_norm_stats_bf16(None, 1, 64, 64, 0, one, one, one, 1 << 20, None) == E_NULL
+    # inconsistent shapes
+    bad = L.ConvDesc(0, 64, 8, 8, 64, 8, 8, 3, 3, 1, 1, 1)
+    assert lib.vcg_conv2d_fwd(ctypes.byref(bad), one, one, one, None, None) == E_SHAPE
+    assert lib.vcg_conv2d_bf16_fwd(ctypes.byref(bad), one, one, one, None, None) == E_SHAPE
+    assert lib.vcg_maxpool2x2_fwd(one, one, 1, 3, 1, 8, None) == E_SHAPE
+    assert lib.vcg_pack_conv_kernel_bf16(one, 0, 64, 64, 1, 0, one, None) == E_SHAPE
+    # shapes that are not instantiated
+    d7 = L.ConvDesc(1, 64, 8, 8, 64, 8, 8, 7, 7, 1, 3, 3)
+    assert lib.vcg_conv2d_fwd(ctypes.byref(d7), one, one, one, None, None) == E_UNSUPPORTED
+    d128 = L.ConvDesc(1, 128, 8, 8, 64, 8, 8, 3, 3, 1, 1, 1)
+    assert lib.vcg_conv2d_bf16_fwd(ctypes.byref(d128), one, one, one, None, None) == E_UNSUPPORTED
+    assert lib.vcg_conv2d_bf16_wgrad(ctypes.byref(d128), one, one, one, None, one, 1 << 30, None) == E_UNSUPPORTED
+    assert lib.vcg_norm_stats_bf16(one, 1, 60, 64, 0, one, one, one, 1 << 20, None) == E_UNSUPPORTED       # c % 8 != 0
+    ep = L.EpilogueBf16(None, None, L.ACT_TANH, 0.0, None, None)
+    assert lib.vcg_conv2d_bf16_fwd(ctypes.byref(d), one, one, one, ctypes.byref(ep), None) == E_UNSUPPORTED
+    ep = L.EpilogueBf16(None, None, L.ACT_PRELU, 0.0, None, None)                                          # PReLU without its slopes
+    assert lib.vcg_conv2d_bf16_fwd(ctypes.byref(d), one, one, one, ctypes.byref(ep), None) == E_NULL
+    # workspace too small
+    need = lib.vcg_conv2d_bf16_wgrad_workspace_bytes(ctypes.byref(d))
+    assert need > 0 and lib.vcg_conv2d_bf16_wgrad(ctypes.byref(d), one, one, one, None, one, need - 1, None) == E_WORKSPACE
+    need = lib.vcg_norm_act_bwd_bf16_workspace_bytes(2, 64, 64, 0)
+    assert lib.vcg_norm_act_bwd_bf16(one, one, 2, 64, 64, 0, one, one, None, None, 0, 0.0, None, 1, one, None, None, None, one, need - 1, None) == E_WORKSPACE
+    for code in (E_NULL, E_SHAPE, E_UNSUPPORTED, E_WORKSPACE):
+        assert lib.vcg_error_string(code) and lib.vcg_error_string(code) != lib.vcg_error_string(0)
+    # and the Python shim turns them into exceptions
+    with pytest.raises((ValueError, RuntimeError)):
+        L.check(E_SHAPE, "test")
