@@ -521,3 +521,35 @@ def test_final_conv9x9_bf16_dgrad(rt, n, h, w, mask):
     e = rel_err(_to_nchw_f32(rt, dx), ref)
     report("bf16 final conv dgrad 3->256 n=%d %dx%d mask=%s err=%.2e" % (n, h, w, mask, e))
     assert e < TOL_BF16
+
+
+@pytest.mark.parametrize("mode", ["bf16", "bf16+tail"])
+def test_bf16_generator_modes_graph_replay_matches_eager(rt, mode):
+    """the mixed-precision generator modes inside the captured train step: bf16 weight copies are re-packed inside the graph after
+    every Adam update, so the replays reproduce the eagerly launched steps bit for bit"""
+    from upscaler import model as PM, _engine as E
+
+    def run(graph):
+        G = PM.make_upscaler_orig((64, 64, 3), kernel_size=3, upscale_factor=2, res_block_num=2, seed=7, trunk_dtype=mode)
+        D = PM.make_discriminator_patchgan_70((64, 64, 3), seed=11)
+        _, _, gan = PM.make_and_compile_gan2(G, D, (32, 32, 3), (64, 64, 3), "mse", 1.0, lambda: PM.WassersteinLosses(), 1e-2,
+                                             optimizer=PM.Adam())
+        tr = gan.trainer
+        rng = np.random.RandomState(5)
+        steps = [(E.to_device_nchw(rt, rng.randint(0, 256, (2, 32, 32, 3)) / 127.5 - 1),
+                  E.to_device_nchw(rt, rng.randint(0, 256, (2, 64, 64, 3)) / 127.5 - 1)) for _ in range(4)]
+        out = []
+        if graph:
+            tr.capture_train_step(*steps[0])
+            for a, b in steps[1:]:
+                out.append(tr.train_step_graph(a, b))
+        else:
+            for a, b in steps:
+                out.append(tr.train_step(a, b))
+            out = out[1:]
+        return out, G.ps.params.clone(), D.ps.params.clone()
+    oe, ge, de = run(False)
+    og, gg, dg = run(True)
+    assert oe == og, (oe, og)
+    assert torch.equal(ge, gg) and torch.equal(de, dg)
+    assert all(np.isfinite(v) for step in og for v in step)
