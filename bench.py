@@ -95,6 +95,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=8, help="frames per GPU")
     ap.add_argument("--lr-size", type=int, default=256, help="low-res frame edge (output is 2x)")
+    ap.add_argument("--lr-width", type=int, default=0, help="low-res frame width if not square (e.g. --lr-size 540 --lr-width 960: config C4's frames)")
     ap.add_argument("--res-blocks", type=int, default=9)
     ap.add_argument("--disc", default="patchgan", choices=["patchgan", "simple"])
     ap.add_argument("--content", default="mse", choices=["mse", "vgg_mse"],
@@ -127,18 +128,19 @@ def main():
     group = _dist.init_from_env("gloo" if rehearsal else "nccl") if world > 1 else None
 
     h = args.lr_size
-    G = PM.make_upscaler_orig((2 * h, 2 * h, 3), kernel_size=3, upscale_factor=2, res_block_num=args.res_blocks, seed=7,
+    w = args.lr_width or h
+    G = PM.make_upscaler_orig((2 * h, 2 * w, 3), kernel_size=3, upscale_factor=2, res_block_num=args.res_blocks, seed=7,
                               trunk_dtype=args.trunk_dtype)
-    D = (PM.make_discriminator_patchgan_70((2 * h, 2 * h, 3), seed=11) if args.disc == "patchgan"
-         else PM.make_discriminator_simple_512((2 * h, 2 * h, 3), seed=11))
+    D = (PM.make_discriminator_patchgan_70((2 * h, 2 * w, 3), seed=11) if args.disc == "patchgan"
+         else PM.make_discriminator_simple_512((2 * h, 2 * w, 3), seed=11))
     if group is not None:                     # identical replicas: broadcast rank 0's weights
         for m in (G, D):
             _dist.broadcast_(m.ps.params, group)
             _dist.broadcast_(m.ps.state, group)
             m.refresh()
-    content = "mse" if args.content == "mse" else PM.VGG_MSE_LOSS((2 * h, 2 * h, 3), 0.1, vgg19="random").loss
+    content = "mse" if args.content == "mse" else PM.VGG_MSE_LOSS((2 * h, 2 * w, 3), 0.1, vgg19="random").loss
     gen_train, disc_train, gan_train = PM.make_and_compile_gan2(
-        G, D, (h, h, 3), (2 * h, 2 * h, 3), content, 1.0, lambda: PM.WassersteinLosses(), 1e-5, optimizer=PM.Adam(),
+        G, D, (h, w, 3), (2 * h, 2 * w, 3), content, 1.0, lambda: PM.WassersteinLosses(), 1e-5, optimizer=PM.Adam(),
         process_group=group)
     trainer = gan_train.trainer
     rt = E.Runtime.get()
@@ -146,8 +148,8 @@ def main():
     # synthetic frames: uint8 U{0..255} -> v/127.5-1 (data.py:266-270), resident in HBM before timing
     g1 = torch.Generator().manual_seed(1234 + rank)
     g2 = torch.Generator().manual_seed(4321 + rank)
-    lr = PD.frames_u8_to_device(torch.randint(0, 256, (args.batch, h, h, 3), generator=g1, dtype=torch.uint8))
-    hr = PD.frames_u8_to_device(torch.randint(0, 256, (args.batch, 2 * h, 2 * h, 3), generator=g2, dtype=torch.uint8))
+    lr = PD.frames_u8_to_device(torch.randint(0, 256, (args.batch, h, w, 3), generator=g1, dtype=torch.uint8))
+    hr = PD.frames_u8_to_device(torch.randint(0, 256, (args.batch, 2 * h, 2 * w, 3), generator=g2, dtype=torch.uint8))
 
     def sync():
         torch.cuda.synchronize()
@@ -203,13 +205,13 @@ def main():
 
     # roofline of the dominant kernel
     mean_ms, launches = prof.mean_ms(dom_tags)
-    flop_per_launch = 2.0 * (64 * 64 * 9) * (h * h) * args.batch           # 2 * MAC/pixel * pixels * frames
+    flop_per_launch = 2.0 * (64 * 64 * 9) * (h * w) * args.batch           # 2 * MAC/pixel * pixels * frames
     roof = None
     if mean_ms:
         ach = flop_per_launch / (mean_ms * 1e-3) / 1e12
         roof = {"bound": "mfma", "kernel": "conv_fwd_kernel<3,3,1,8> (64->64 3x3 trunk conv, forward + dgrad)",
                 "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": TRUNK_CONV_HBM_BYTES if (h, args.batch) == (256, 8) else None,
+                "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": TRUNK_CONV_HBM_BYTES if (h, w, args.batch) == (256, 256, 8) else None,
                 "traffic_note": "HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction, calibrated on a "
                                 "128 MiB streaming read; + WRITE_SIZE): profiles/r01_pmc_trunk_conv.txt; algorithmic bytes 268.6e6",
                 "launches_timed": launches, "mean_launch_ms": round(mean_ms, 4),
@@ -217,20 +219,20 @@ def main():
 
     if rank == 0:
         out = {
-            "metric": METRIC, "value": round(frames / dt, 3), "unit": "frames/s", "n_gpus": world,
+            "metric": METRIC if (h, w) == (256, 256) else METRIC.replace("256->512", "%dx%d->%dx%d" % (h, w, 2 * h, 2 * w)), "value": round(frames / dt, 3), "unit": "frames/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if args.trunk_dtype == "fp32" else "generator %s activations bf16 / f32 elsewhere (mixed; not C2)" % ("trunk" if args.trunk_dtype == "bf16" else "trunk + up-sampling + final conv"), "data": "synthetic",
-            "config": {"workload": "C2: make_upscaler_orig((%d,%d,3),k=3,x2,res=%d) + %s, batch %d/GPU, "
+            "config": {"workload": ("C2" if (h, w) == (256, 256) else "C4 frame size" if (h, w) == (540, 960) else "custom size") + ": make_upscaler_orig((%d,%d,3),k=3,x2,res=%d) + %s, batch %d/GPU, "
                                    "gan2 wiring, Wasserstein + %s, faithful 3-call step incl. predict pass"
-                                   % (2 * h, 2 * h, args.res_blocks, "PatchGAN-70" if args.disc == "patchgan" else "simple_512",
+                                   % (2 * h, 2 * w, args.res_blocks, "PatchGAN-70" if args.disc == "patchgan" else "simple_512",
                                       args.batch, "pixel-MSE" if args.content == "mse" else "VGG_MSE_LOSS(0.1), random VGG19 weights"),
-                       "global_batch": args.batch * world, "frame": "%dx%d->%dx%d" % (h, h, 2 * h, 2 * h),
+                       "global_batch": args.batch * world, "frame": "%dx%d->%dx%d" % (h, w, 2 * h, 2 * w),
                        "parallelism": "dp%d" % world, "launch": ("hipGraph replay" if world == 1 else "3 hipGraphs per step around the 2 RCCL all-reduces") if use_graph else "eager"},
             "last_losses": [round(float(v), 6) for v in losses],
             "roofline": roof,
         }
-        if world == 1 and not args.no_cpu_baseline and args.content == "mse" and args.trunk_dtype == "fp32":
+        if world == 1 and not args.no_cpu_baseline and args.content == "mse" and args.trunk_dtype == "fp32" and w == h:
             out["cpu_baseline"] = cpu_baseline(args.res_blocks, args.cpu_sample_batch, h)
         print(json.dumps(out), flush=True)
     if group is not None:
