@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--lr-size", type=int, default=256)
+    ap.add_argument("--lr-width", type=int, default=0, help="non-square frames, e.g. --lr-size 540 --lr-width 960 (config C4's frame size)")
     ap.add_argument("--res-blocks", type=int, default=9)
     args = ap.parse_args()
 
@@ -30,12 +31,13 @@ def main():
     from upscaler import model as PM
 
     h, B = args.lr_size, args.batch
-    G = PM.make_upscaler_orig((2 * h, 2 * h, 3), kernel_size=3, upscale_factor=2, res_block_num=args.res_blocks, seed=7)
+    w = args.lr_width or h
+    G = PM.make_upscaler_orig((2 * h, 2 * w, 3), kernel_size=3, upscale_factor=2, res_block_num=args.res_blocks, seed=7)
     inf = G.to_inference_bf16()
     rt = E.Runtime.get()
     g1 = torch.Generator().manual_seed(1234)
-    x = PD.frames_u8_to_device(torch.randint(0, 256, (B, h, h, 3), generator=g1, dtype=torch.uint8))
-    inf.capture(B, h, h)
+    x = PD.frames_u8_to_device(torch.randint(0, 256, (B, h, w, 3), generator=g1, dtype=torch.uint8))
+    inf.capture(B, h, w)
     for _ in range(args.warmup):
         inf.replay(x)
     torch.cuda.synchronize()
@@ -62,18 +64,18 @@ def main():
     inf._conv = orig
     ms = [a.elapsed_time(b) for a, b, _ in evs]
     mean_ms = sum(ms) / len(ms)
-    tensor_bytes = B * h * h * 64 * 2
+    tensor_bytes = B * h * w * 64 * 2
     nres = sum(1 for _, _, r in evs if r)
     alg_bytes = (2 * len(evs) + nres) / len(evs) * tensor_bytes + 9 * 64 * 64 * 2        # in + out (+ residual) + weights
     ach = alg_bytes / (mean_ms * 1e-3) / 1e9
-    flop = 2.0 * 64 * 64 * 9 * h * h * B
+    flop = 2.0 * 64 * 64 * 9 * h * w * B
     out = {
-        "metric": "upscaled frames/s (inference, generator only) at 256->512", "value": round(B * args.steps / dt, 1), "unit": "frames/s",
+        "metric": "upscaled frames/s (inference, generator only) at %s" % ("256->512" if (h, w) == (256, 256) else "%dx%d->%dx%d" % (h, w, 2 * h, 2 * w)), "value": round(B * args.steps / dt, 1), "unit": "frames/s",
         "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
         "config": {"workload": "C5: make_upscaler_orig((%d,%d,3),k=3,x2,res=%d).predict, BN folded, bf16 NHWC activations, fp32 accumulate, "
-                               "batch %d, one hipGraph replay per batch" % (2 * h, 2 * h, args.res_blocks, B), "global_batch": B,
-                   "frame": "%dx%d->%dx%d" % (h, h, 2 * h, 2 * h), "launch": "hipGraph replay"},
+                               "batch %d, one hipGraph replay per batch" % (2 * h, 2 * w, args.res_blocks, B), "global_batch": B,
+                   "frame": "%dx%d->%dx%d" % (h, w, 2 * h, 2 * w), "launch": "hipGraph replay"},
         "roofline": {"bound": "hbm", "kernel": "conv3x3_c64_bf16_kernel (64->64 3x3 trunk convolution, bf16 NHWC)", "achieved": round(ach, 1),
                      "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": None,
                      "launches_timed": len(evs), "mean_launch_ms": round(mean_ms, 4), "bytes_per_launch": alg_bytes,
