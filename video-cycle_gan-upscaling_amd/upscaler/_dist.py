@@ -26,7 +26,7 @@ def init_from_env(backend=None):
 
 def allreduce_mean(flat, group):
     """in-place mean over the ranks of one flat fp32 buffer (the model's whole gradient bucket)."""
-    if group is None:
+    if group is None or flat.numel() == 0:
         return flat
     if flat.is_cuda and dist.get_backend(group) == "gloo":
         # test rig only (several gloo ranks sharing one GPU, tests/test_dp_gpu.py): stage through the host
@@ -40,7 +40,7 @@ def allreduce_mean(flat, group):
 
 
 def broadcast_(flat, group, src=0):
-    if group is not None:
+    if group is not None and flat.numel() > 0:        # (a model without BatchNormalization has an empty state buffer)
         if flat.is_cuda and dist.get_backend(group) == "gloo":
             host = flat.detach().cpu()
             dist.broadcast(host, src=src, group=group)
