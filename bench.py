@@ -10,12 +10,20 @@ make_and_compile_gan2 wiring with WassersteinLosses, pixel-MSE content loss, los
 A step is one iteration of the reference loop body (train_gan3.py:346-354): gen_train.predict ->
 disc_train.train_on_batch -> gan_train.train_on_batch, on synthetic frames already resident in HBM.
 
+Secondary lines (same JSON format):
+    --disc simple             the reference's own make_discriminator_simple_512 instead of the PatchGAN
+    --kernel-size 5           the reference's default residual-block kernel (model.py:267)
+    --gan-losses rel --disc-activation bi-log      the reference's default loss configuration (train_gan3.py:58,62-63)
+    --dtype bf16              C3/C4's arithmetic: bf16 activations in G and D, fp32 accumulation / statistics / master weights
+    --config c5               BASELINE.json configs[4]: inference-only generator, batch 32, bf16, one hipGraph replay per batch
+
 Prints ONE JSON line (rank 0).  Extra objects:
-  roofline     -- the dominant kernel (3x3 64->64 trunk convolution, forward and its data gradient run
-                  the same kernel): algorithmic FLOPs per launch / mean launch duration measured with HIP
-                  events on the launch stream inside the timed region, against the fp32 MFMA peak.
+  roofline     -- the dominant kernel: algorithmic FLOPs (or bytes) per launch / mean launch duration measured with HIP
+                  events on the launch stream, against the peak that bounds it; `traffic` = measured HBM bytes per launch
+                  looked up BY KERNEL NAME AND SHAPE in profiles/pmc_traffic.json (written by scripts/pmc_to_json.py from
+                  separate rocprofv3 --pmc passes), null when no PMC record matches the workload.
   cpu_baseline -- the CPU oracle (a port: the Keras/TF reference cannot run offline) timed on this
-                  host's cores on a bounded sample of the same workload.
+                  host's cores on a bounded sample of the same workload (1 warm-up + 2 timed steps).
 """
 import argparse
 import json
@@ -30,11 +38,9 @@ for p in (ROOT, PKG):
         sys.path.insert(0, p)
 
 PEAK_F32_MFMA_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+PEAK_BF16_MFMA_TFLOPS = 2500.0      # same guide: ~2.5 PF dense
+PEAK_HBM_GBS = 8000.0               # same guide: HBM3E 8.0 TB/s spec
 METRIC = "upscaled frames/s (train step, G+D fwd+bwd) at 256->512"
-# HBM traffic of one launch of the dominant kernel at the C2 shape, measured with rocprofv3 PMC counters in
-# separate passes (scripts/pmc_kbench.sh "trunk 3x3"): FETCH_SIZE 141.2 MiB x 2 (gfx950 reports half of a
-# coalesced read; calibrated on stats_partial_kernel reading 128 MiB -> 64.1) + WRITE_SIZE 128.0 MiB
-TRUNK_CONV_HBM_BYTES = int((2 * 141.2 + 128.0) * 1024 * 1024)
 
 
 class KernelProf:
@@ -51,6 +57,18 @@ class KernelProf:
         return (tot / cnt if cnt else None), cnt
 
 
+def pmc_traffic(kernel, shape_key):
+    """measured HBM bytes per launch of `kernel` at `shape_key` from profiles/pmc_traffic.json, or (None, None)"""
+    try:
+        recs = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["kernels"]
+    except (OSError, ValueError, KeyError):
+        return None, None
+    for r in recs:
+        if r["kernel"] == kernel and r["shape"] == shape_key:
+            return int(r["fetch_bytes"] + r["write_bytes"]), r
+    return None, None
+
+
 def _host_cores():
     """cores this process may actually use: cgroup CPU quota if set, else the affinity mask (a GPU box
     exposes all host cores but grants a share -- 16 per GPU on this pool)"""
@@ -64,28 +82,130 @@ def _host_cores():
     return max(1, min(n, int(os.environ.get("VCG_CPU_THREADS", "16"))))
 
 
-def cpu_baseline(res_blocks, sample_batch, lr_hw):
-    """One train step of the CPU oracle (torch CPU fp32, all host cores) on `sample_batch` frames of the
-    same models / frame size."""
-    import numpy as np
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(args, h, w):
+    """The CPU oracle (torch CPU fp32, this host's core share) on `--cpu-sample-batch` frames of the same models / frame
+    size / losses: 1 untimed warm-up step, then 2 timed train steps."""
     import torch
     from oracle import models as OM, train as OT
     torch.set_num_threads(_host_cores())
-    h = lr_hw
-    gw = OM.to_torch(OM.init_upscaler_orig((2 * h, 2 * h, 3), 3, 64, 2, res_blocks, seed=7))
-    dw = OM.to_torch(OM.init_discriminator_patchgan_70((2 * h, 2 * h, 3), seed=11))
-    orc = OT.GanOracle(lambda w, x, t: OM.upscaler_orig_forward(w, x, t, res_blocks, 2), gw,
-                       lambda w, x, t: OM.discriminator_patchgan_70_forward(w, x, t), dw,
-                       discriminator_loss_weight=1e-5)
+    nb, k, res = args.cpu_sample_batch, args.kernel_size, args.res_blocks
+    gw = OM.to_torch(OM.init_upscaler_orig((2 * h, 2 * w, 3), k, 64, 2, res, seed=7))
+    if args.disc == "patchgan":
+        dw = OM.to_torch(OM.init_discriminator_patchgan_70((2 * h, 2 * w, 3), seed=11))
+        df = lambda wt, x, t: OM.discriminator_patchgan_70_forward(wt, x, t, activation=args.disc_activation)
+    else:
+        dw = OM.to_torch(OM.init_discriminator_512((2 * h, 2 * w, 3), "simple", seed=11))
+        df = lambda wt, x, t: OM.discriminator_512_forward(wt, x, t, activation=args.disc_activation)
+    orc = OT.GanOracle(lambda wt, x, t: OM.upscaler_orig_forward(wt, x, t, res, 2), gw, df, dw, losses=args.gan_losses,
+                       loss_activation="log-sigm", discriminator_loss_weight=1e-5)
     g = torch.Generator().manual_seed(1234)
-    lr = torch.randint(0, 256, (sample_batch, h, h, 3), generator=g).float() / 127.5 - 1
-    hr = torch.randint(0, 256, (sample_batch, 2 * h, 2 * h, 3), generator=g).float() / 127.5 - 1
+    lr = torch.randint(0, 256, (nb, h, w, 3), generator=g).float() / 127.5 - 1
+    hr = torch.randint(0, 256, (nb, 2 * h, 2 * w, 3), generator=g).float() / 127.5 - 1
+    orc.train_step(lr, hr)                       # warm-up (allocator, oneDNN primitive caches)
+    timed = 2
     t0 = time.perf_counter()
-    orc.train_step(lr, hr)
+    for _ in range(timed):
+        orc.train_step(lr, hr)
     dt = time.perf_counter() - t0
-    return {"value": round(sample_batch / dt, 4), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "1 train step (predict + D step + G step) of the torch-CPU fp32 oracle on %d frame(s) %dx%d->%dx%d, "
-                      "same models; %.1f s" % (sample_batch, h, h, 2 * h, 2 * h, dt)}
+    return {"value": round(nb * timed / dt, 4), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+            "cpu": _cpu_model(),
+            "sample": "%d timed train steps (predict + D step + G step) after 1 warm-up step of the torch-CPU fp32 oracle on %d "
+                      "frame(s) %dx%d->%dx%d, same models and losses; %.1f s timed" % (timed, nb, h, w, 2 * h, 2 * w, dt)}
+
+
+def cpu_baseline_c5(args, h, w):
+    import torch
+    from oracle import models as OM
+    torch.set_num_threads(_host_cores())
+    gw = OM.to_torch(OM.init_upscaler_orig((2 * h, 2 * w, 3), 3, 64, 2, args.res_blocks, seed=7))
+    g = torch.Generator().manual_seed(1234)
+    nb = 4
+    x = torch.randint(0, 256, (nb, h, w, 3), generator=g).float() / 127.5 - 1
+    with torch.no_grad():
+        OM.upscaler_orig_forward(gw, x, False, args.res_blocks, 2)
+        t0 = time.perf_counter()
+        for _ in range(3):
+            OM.upscaler_orig_forward(gw, x, False, args.res_blocks, 2)
+        dt = time.perf_counter() - t0
+    return {"value": round(3 * nb / dt, 3), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port", "cpu": _cpu_model(),
+            "sample": "3 timed predict passes of %d frames after 1 warm-up, torch-CPU fp32 oracle, same generator; %.1f s" % (nb, dt)}
+
+
+def run_c5(args):
+    """BASELINE.json configs[4]: generator.predict only, bf16 NHWC activations, BN folded, one hipGraph replay per batch"""
+    import torch
+    from upscaler import _engine as E
+    from upscaler import data as PD
+    from upscaler import model as PM
+
+    h, B = args.lr_size, args.batch or 32
+    w = args.lr_width or h
+    G = PM.make_upscaler_orig((2 * h, 2 * w, 3), kernel_size=3, upscale_factor=2, res_block_num=args.res_blocks, seed=7)
+    inf = G.to_inference_bf16()
+    g1 = torch.Generator().manual_seed(1234)
+    x = PD.frames_u8_to_device(torch.randint(0, 256, (B, h, w, 3), generator=g1, dtype=torch.uint8))
+    inf.capture(B, h, w)
+    for _ in range(args.warmup):
+        inf.replay(x)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        inf.replay(x)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+
+    # dominant kernel: the 64->64 3x3 trunk convolution (2*res+1 launches per batch); HIP events around eager launches
+    evs = []
+    orig = inf._conv
+
+    def timed(*a):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        orig(*a)
+        e1.record()
+        evs.append((e0, e1, a[7] is not None))
+    inf._conv = timed
+    for _ in range(3):
+        inf.forward(x)
+    torch.cuda.synchronize()
+    inf._conv = orig
+    ms = [a.elapsed_time(b) for a, b, _ in evs]
+    mean_ms = sum(ms) / len(ms)
+    tensor_bytes = B * h * w * 64 * 2
+    nres = sum(1 for _, _, r in evs if r)
+    alg_bytes = (2 * len(evs) + nres) / len(evs) * tensor_bytes + 9 * 64 * 64 * 2        # in + out (+ residual) + weights
+    ach = alg_bytes / (mean_ms * 1e-3) / 1e9
+    flop = 2.0 * 64 * 64 * 9 * h * w * B
+    kname = "conv3x3_c64_bf16_kernel"
+    traffic, rec = pmc_traffic(kname, "n%d_%dx%d" % (B, h, w))
+    out = {
+        "metric": "upscaled frames/s (inference, generator only) at %s" % ("256->512" if (h, w) == (256, 256) else "%dx%d->%dx%d" % (h, w, 2 * h, 2 * w)),
+        "value": round(B * args.steps / dt, 1), "unit": "frames/s",
+        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": "C5: make_upscaler_orig((%d,%d,3),k=3,x2,res=%d).predict, BN folded, bf16 NHWC activations, fp32 accumulate, "
+                               "batch %d, one hipGraph replay per batch" % (2 * h, 2 * w, args.res_blocks, B), "global_batch": B,
+                   "frame": "%dx%d->%dx%d" % (h, w, 2 * h, 2 * w), "parallelism": "dp1", "launch": "hipGraph replay"},
+        "roofline": {"bound": "hbm", "kernel": kname + " (64->64 3x3 trunk convolution, bf16 NHWC)", "achieved": round(ach, 1),
+                     "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": traffic,
+                     "traffic_source": rec and rec.get("source"),
+                     "launches_timed": len(evs), "mean_launch_ms": round(mean_ms, 4), "bytes_per_launch": alg_bytes,
+                     "mfma_tflops": round(flop / (mean_ms * 1e-3) / 1e12, 1), "mfma_frac": round(flop / (mean_ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4),
+                     "how": "HIP events around the eager launches of 3 passes run right after the timed graph replays"},
+    }
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline_c5(args, h, w)
+    print(json.dumps(out), flush=True)
 
 
 def main():
@@ -93,20 +213,30 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=8, help="frames per GPU")
+    ap.add_argument("--config", default="c2", choices=["c2", "c5"], help="c2: the train step (headline); c5: inference-only generator, bf16, hipGraph")
+    ap.add_argument("--batch", type=int, default=0, help="frames per GPU (default 8; 32 for --config c5)")
     ap.add_argument("--lr-size", type=int, default=256, help="low-res frame edge (output is 2x)")
     ap.add_argument("--lr-width", type=int, default=0, help="low-res frame width if not square (e.g. --lr-size 540 --lr-width 960: config C4's frames)")
     ap.add_argument("--res-blocks", type=int, default=9)
+    ap.add_argument("--kernel-size", type=int, default=3, choices=[3, 5], help="residual-block / up-sampling kernel (reference default: 5)")
     ap.add_argument("--disc", default="patchgan", choices=["patchgan", "simple"])
+    ap.add_argument("--disc-activation", default="none", choices=["none", "sigmoid", "log-sigm", "tanh", "bi-log"])
+    ap.add_argument("--gan-losses", default="wass", choices=["wass", "rel"], help="WassersteinLosses (C2 as SURVEY 8d defines it) or RelativisticLosses('log-sigm')")
     ap.add_argument("--content", default="mse", choices=["mse", "vgg_mse"],
                     help="content loss: pixel MSE (C2 as SURVEY 8d defines it) or the reference's default VGG_MSE_LOSS form with "
                          "seeded random VGG19 weights (ImageNet weights cannot be fetched offline)")
-    ap.add_argument("--trunk-dtype", default="fp32", choices=["fp32", "bf16", "bf16+tail"],
-                    help="bf16: the generator's residual trunk trains on bf16 activations (mixed precision; NOT config C2, reported as such)")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"], help="bf16: activations of G and D in bf16 (C3/C4's arithmetic)")
+    ap.add_argument("--trunk-dtype", default=None, choices=["fp32", "bf16", "bf16+tail"],
+                    help="partial mixed precision (generator only); superseded by --dtype bf16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying one hipGraph per step")
     ap.add_argument("--cpu-sample-batch", type=int, default=2)
     args = ap.parse_args()
+    if args.config == "c5":
+        if args.gpus != 1:
+            raise SystemExit("--config c5 is a single-GPU configuration")
+        return run_c5(args)
+    args.batch = args.batch or 8
 
     import torch
     import torch.distributed as dist
@@ -129,19 +259,23 @@ def main():
 
     h = args.lr_size
     w = args.lr_width or h
-    G = PM.make_upscaler_orig((2 * h, 2 * w, 3), kernel_size=3, upscale_factor=2, res_block_num=args.res_blocks, seed=7,
-                              trunk_dtype=args.trunk_dtype)
-    D = (PM.make_discriminator_patchgan_70((2 * h, 2 * w, 3), seed=11) if args.disc == "patchgan"
-         else PM.make_discriminator_simple_512((2 * h, 2 * w, 3), seed=11))
+    k = args.kernel_size
+    bf16 = args.dtype == "bf16"
+    trunk_dtype = args.trunk_dtype or ("bf16+tail" if bf16 else "fp32")
+    G = PM.make_upscaler_orig((2 * h, 2 * w, 3), kernel_size=k, upscale_factor=2, res_block_num=args.res_blocks, seed=7,
+                              trunk_dtype=trunk_dtype)
+    dkw = {"dtype": "bf16"} if bf16 else {}
+    D = (PM.make_discriminator_patchgan_70((2 * h, 2 * w, 3), args.disc_activation, seed=11, **dkw) if args.disc == "patchgan"
+         else PM.make_discriminator_simple_512((2 * h, 2 * w, 3), args.disc_activation, seed=11, **dkw))
     if group is not None:                     # identical replicas: broadcast rank 0's weights
         for m in (G, D):
             _dist.broadcast_(m.ps.params, group)
             _dist.broadcast_(m.ps.state, group)
             m.refresh()
     content = "mse" if args.content == "mse" else PM.VGG_MSE_LOSS((2 * h, 2 * w, 3), 0.1, vgg19="random").loss
+    fac = (lambda: PM.WassersteinLosses()) if args.gan_losses == "wass" else (lambda: PM.RelativisticLosses(loss_activation="log-sigm"))
     gen_train, disc_train, gan_train = PM.make_and_compile_gan2(
-        G, D, (h, w, 3), (2 * h, 2 * w, 3), content, 1.0, lambda: PM.WassersteinLosses(), 1e-5, optimizer=PM.Adam(),
-        process_group=group)
+        G, D, (h, w, 3), (2 * h, 2 * w, 3), content, 1.0, fac, 1e-5, optimizer=PM.Adam(), process_group=group)
     trainer = gan_train.trainer
     rt = E.Runtime.get()
 
@@ -157,8 +291,8 @@ def main():
             dist.barrier(group=group)
             torch.cuda.synchronize()
 
-    # One hipGraph per step (Wasserstein losses: no host read inside the step).  Under DP the step is three graphs
-    # cut at the two exchange points, with the two RCCL all-reduces issued eagerly between the replays.
+    # One hipGraph per step (no host read inside the step, for any of the reference's losses).  Under DP the step is cut at
+    # its collectives into several graphs, with the RCCL all-reduces issued eagerly between the replays.
     use_graph = not args.no_graph
     step = trainer.train_step
     if use_graph:
@@ -175,6 +309,7 @@ def main():
             step = trainer.train_step_graph
     for _ in range(args.warmup):
         step(lr, hr)
+    bf16_trunk = trunk_dtype != "fp32" and k == 3
     dom_tags = ("trunk_conv", "trunk_conv_dgrad")
     if not use_graph:
         rt.prof = KernelProf(dom_tags)
@@ -203,37 +338,53 @@ def main():
     dt = float(dt_t.item())
     frames = args.batch * world * args.steps
 
-    # roofline of the dominant kernel
+    # roofline of the dominant kernel: the 64->64 trunk convolution (forward and data gradient run the same kernel)
     mean_ms, launches = prof.mean_ms(dom_tags)
-    flop_per_launch = 2.0 * (64 * 64 * 9) * (h * w) * args.batch           # 2 * MAC/pixel * pixels * frames
+    flop_per_launch = 2.0 * (64 * 64 * k * k) * (h * w) * args.batch           # 2 * MAC/pixel * pixels * frames
+    shape_key = "n%d_%dx%d" % (args.batch, h, w)
     roof = None
     if mean_ms:
-        ach = flop_per_launch / (mean_ms * 1e-3) / 1e12
-        roof = {"bound": "mfma", "kernel": "conv_fwd_kernel<3,3,1,8> (64->64 3x3 trunk conv, forward + dgrad)",
-                "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": TRUNK_CONV_HBM_BYTES if (h, w, args.batch) == (256, 256, 8) else None,
-                "traffic_note": "HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction, calibrated on a "
-                                "128 MiB streaming read; + WRITE_SIZE): profiles/r01_pmc_trunk_conv.txt; algorithmic bytes 268.6e6",
-                "launches_timed": launches, "mean_launch_ms": round(mean_ms, 4),
-                "flop_per_launch": flop_per_launch, "how": roof_note}
+        tfl = flop_per_launch / (mean_ms * 1e-3) / 1e12
+        if bf16_trunk:
+            # bf16 NHWC: 142 KB of traffic per 16x32-pixel tile against 9.2k MFMA cycles -- at the ridge; priced against HBM
+            kname = "conv3x3_c64_bf16_kernel"
+            alg_bytes = 2 * args.batch * h * w * 64 * 2 + 9 * 64 * 64 * 2
+            ach = alg_bytes / (mean_ms * 1e-3) / 1e9
+            roof = {"bound": "hbm", "kernel": kname + " (64->64 3x3 trunk conv on bf16 NHWC, forward + dgrad)", "achieved": round(ach, 1),
+                    "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBS, 4), "bytes_per_launch": alg_bytes,
+                    "mfma_tflops": round(tfl, 1), "mfma_frac": round(tfl / PEAK_BF16_MFMA_TFLOPS, 4)}
+        else:
+            kname = "conv_fwd_kernel<%d, %d, 1, 8, %d>" % (k, k, 2 if k == 3 else 1)
+            roof = {"bound": "mfma", "kernel": kname + " (64->64 %dx%d trunk conv, forward + dgrad)" % (k, k),
+                    "achieved": round(tfl, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(tfl / PEAK_F32_MFMA_TFLOPS, 4), "flop_per_launch": flop_per_launch}
+        traffic, rec = pmc_traffic(kname, shape_key)
+        roof.update({"traffic": traffic, "traffic_source": rec and rec.get("source"),
+                     "algorithmic_bytes": roof.get("bytes_per_launch", 2 * args.batch * h * w * 64 * 4 + k * k * 64 * 64 * 4),
+                     "launches_timed": launches, "mean_launch_ms": round(mean_ms, 4), "how": roof_note})
 
     if rank == 0:
+        dts = "f32" if trunk_dtype == "fp32" else ("bf16" if bf16 else "generator %s activations bf16 / f32 elsewhere (mixed; not C2)"
+                                                   % ("trunk" if trunk_dtype == "bf16" else "trunk + up-sampling + final conv"))
+        wl = "C2" if (h, w) == (256, 256) and not bf16 else "C3 per-GPU shard" if (h, w) == (256, 256) else "C4 frame size" if (h, w) == (540, 960) else "custom size"
         out = {
             "metric": METRIC if (h, w) == (256, 256) else METRIC.replace("256->512", "%dx%d->%dx%d" % (h, w, 2 * h, 2 * w)), "value": round(frames / dt, 3), "unit": "frames/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if args.trunk_dtype == "fp32" else "generator %s activations bf16 / f32 elsewhere (mixed; not C2)" % ("trunk" if args.trunk_dtype == "bf16" else "trunk + up-sampling + final conv"), "data": "synthetic",
-            "config": {"workload": ("C2" if (h, w) == (256, 256) else "C4 frame size" if (h, w) == (540, 960) else "custom size") + ": make_upscaler_orig((%d,%d,3),k=3,x2,res=%d) + %s, batch %d/GPU, "
-                                   "gan2 wiring, Wasserstein + %s, faithful 3-call step incl. predict pass"
-                                   % (2 * h, 2 * w, args.res_blocks, "PatchGAN-70" if args.disc == "patchgan" else "simple_512",
-                                      args.batch, "pixel-MSE" if args.content == "mse" else "VGG_MSE_LOSS(0.1), random VGG19 weights"),
+            "dtype": dts, "data": "synthetic",
+            "config": {"workload": wl + ": make_upscaler_orig((%d,%d,3),k=%d,x2,res=%d) + %s%s, batch %d/GPU, "
+                                   "gan2 wiring, %s + %s, faithful 3-call step incl. predict pass"
+                                   % (2 * h, 2 * w, k, args.res_blocks, "PatchGAN-70" if args.disc == "patchgan" else "simple_512",
+                                      "" if args.disc_activation == "none" else "(%s)" % args.disc_activation, args.batch,
+                                      "Wasserstein" if args.gan_losses == "wass" else "Relativistic(log-sigm)",
+                                      "pixel-MSE" if args.content == "mse" else "VGG_MSE_LOSS(0.1), random VGG19 weights"),
                        "global_batch": args.batch * world, "frame": "%dx%d->%dx%d" % (h, w, 2 * h, 2 * w),
-                       "parallelism": "dp%d" % world, "launch": ("hipGraph replay" if world == 1 else "3 hipGraphs per step around the 2 RCCL all-reduces") if use_graph else "eager"},
+                       "parallelism": "dp%d" % world, "launch": ("hipGraph replay" if world == 1 else "%d hipGraphs per step around the RCCL all-reduces" % len(trainer._graph)) if use_graph else "eager"},
             "last_losses": [round(float(v), 6) for v in losses],
             "roofline": roof,
         }
-        if world == 1 and not args.no_cpu_baseline and args.content == "mse" and args.trunk_dtype == "fp32" and w == h:
-            out["cpu_baseline"] = cpu_baseline(args.res_blocks, args.cpu_sample_batch, h)
+        if world == 1 and not args.no_cpu_baseline and args.content == "mse" and w == h:
+            out["cpu_baseline"] = cpu_baseline(args, h, w)
         print(json.dumps(out), flush=True)
     if group is not None:
         dist.barrier(group=group)

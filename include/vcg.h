@@ -40,6 +40,8 @@ enum {
 enum { VCG_ACT_NONE = 0, VCG_ACT_LRELU = 1, VCG_ACT_PRELU = 2, VCG_ACT_TANH = 3 };
 enum { VCG_NORM_BATCH = 0, VCG_NORM_INSTANCE = 1 };
 enum { VCG_LOSS_MSE = 0, VCG_LOSS_MAE = 1 };
+/* discriminator output activation (upscaling/upscaler/model.py:885-892) == GanLosses.loss_activation (:172-181) */
+enum { VCG_HEAD_NONE = 0, VCG_HEAD_SIGMOID = 1, VCG_HEAD_LOGSIGM = 2, VCG_HEAD_TANH = 3, VCG_HEAD_BILOG = 4 };
 
 /* A Keras Conv2D / Conv2DTranspose call site.  For Conv2D  (n,cin,h,w) -> (n,cout,oh,ow);
  * pad_top/pad_left are the TF-SAME "before" pads (bottom/right follow from oh/ow).
@@ -146,6 +148,22 @@ int vcg_mean_reduce(const float* x, size_t count, float* out, void* ws, size_t w
 /* content loss value (out[0]) and gradient d/dpred scaled by grad_scale/count */
 int vcg_pixel_loss(const float* pred, const float* target, size_t count, int kind, float grad_scale,
                    float* out, float* dpred, void* ws, size_t ws_bytes, vcg_stream_t stream);
+/* Discriminator output activation: Activation('sigmoid') / Lambda(log(sigmoid)) / Activation('tanh') /
+ * Lambda(x/(1+|x|)*log(|x|+2)) after Dense_3 (upscaling/upscaler/model.py:885-892, 950-957, 1001-1008).
+ * fwd: y = act(z); bwd: dz = dy * act'(z) from the saved PRE-activation z.  kind: VCG_HEAD_*. */
+int vcg_head_act_fwd(const float* z, float* y, size_t count, int kind, vcg_stream_t stream);
+int vcg_head_act_bwd(const float* z, const float* dy, float* dz, size_t count, int kind, vcg_stream_t stream);
+/* GAN losses evaluated on the device from two mean(D(.)) scalars (model.py:220-233 Wasserstein: kind = VCG_HEAD_NONE;
+ * model.py:244-259 relativistic: loss_activation(mean_a - mean_b)):
+ *   delta = (mean_a[0] - (mean_b ? mean_b[0] : 0)) * mean_scale        (mean_scale = 1/ranks when the scalars hold an
+ *                                                                       all-reduce SUM of per-rank means, else 1)
+ *   loss_out[0] = act(delta)                 (optional)
+ *   da[0..na) = act'(delta) * ga ,  db[0..nb) = act'(delta) * gb       -- the broadcast gradients dL/dD(.) of the two
+ *                                                                       batches the means were taken over
+ * No host read: the train step stays capturable in a hipGraph (train_gan3.py:353-354 returns the loss to the host
+ * after the step). */
+int vcg_gan_loss(const float* mean_a, const float* mean_b, float mean_scale, int kind, float* loss_out, float* da, size_t na,
+                 float ga, float* db, size_t nb, float gb, vcg_stream_t stream);
 /* y = value everywhere (broadcast gradient of a mean) */
 int vcg_fill(float* y, size_t count, float value, vcg_stream_t stream);
 /* y = a*x + b*y */
@@ -159,15 +177,16 @@ int vcg_maxpool2x2_bwd(const float* x, const float* dy, float* dx, int n, int c,
 
 /* ---- Adam(): keras.optimizers.Adam defaults, model.py:1026,1066,1130 -------------------------- */
 /* multi-tensor update over one flat parameter buffer; lr_t = lr*sqrt(1-b2^t)/(1-b1^t) is computed
- * by the caller; p -= lr_t * m / (sqrt(v) + eps) */
+ * by the caller; p -= lr_t * m / (sqrt(v) + eps).  The gradient enters as g * grad_scale: 1 for a single process,
+ * 1/ranks when g holds the all-reduce SUM of the data-parallel replicas' buckets (no separate averaging pass). */
 int vcg_adam_keras_multi(float* p, const float* g, float* m, float* v, size_t count, float lr_t,
-                         float beta_1, float beta_2, float eps, vcg_stream_t stream);
+                         float beta_1, float beta_2, float eps, float grad_scale, vcg_stream_t stream);
 
 /* same update with the iteration count kept on the device, so a hipGraph that captured the call replays correctly
  * step after step.  t_dev points to TWO 32-bit words: [0] the int32 iteration count (uses t = t_dev[0] + 1 for the
  * bias correction, then increments it), [1] scratch for lr_t (evaluated once per call, in double, by one thread) */
 int vcg_adam_keras_multi_dev(float* p, const float* g, float* m, float* v, size_t count, float lr,
-                             float beta_1, float beta_2, float eps, int* t_dev, vcg_stream_t stream);
+                             float beta_1, float beta_2, float eps, float grad_scale, int* t_dev, vcg_stream_t stream);
 
 /* ---- frame edge: upscaling/upscaler/data.py:253-270 ------------------------------------------- */
 /* uint8 NHWC -> fp32 NCHW, v/127.5 - 1 */

@@ -53,7 +53,28 @@ def conv2d(x, w_hwio, b, stride=1, padding="same"):
     else:
         pt = pb = pl = pr = int(padding)
     x = F.pad(x, (pl, pr, pt, pb))
-    return F.conv2d(x, w, b, stride=stride)
+    return _conv2d_banded(x, w, b, stride)
+
+
+def _conv2d_banded(x, w, b, stride):
+    """F.conv2d on an already padded input.  torch evaluates float64 convolutions through an unfold buffer of
+    n*cin*kh*kw*oh*ow elements (87 GB for final/conv at 512x512, batch 2): such calls are cut into per-sample bands of
+    output rows (with their kh-1 halo rows) -- the same arithmetic, autograd included."""
+    n, cin, hp, wp = x.shape
+    kh, kw = w.shape[2], w.shape[3]
+    oh, ow = (hp - kh) // stride + 1, (wp - kw) // stride + 1
+    unfold_bytes = cin * kh * kw * oh * ow * x.element_size()
+    if x.dtype != torch.float64 or n * unfold_bytes <= (1 << 30):
+        return F.conv2d(x, w, b, stride=stride)
+    rows = max(1, min(oh, int((1 << 30) // max(unfold_bytes // oh, 1))))
+    out = []
+    for i in range(n):
+        bands = []
+        for r0 in range(0, oh, rows):
+            r1 = min(r0 + rows, oh)
+            bands.append(F.conv2d(x[i:i + 1, :, r0 * stride:(r1 - 1) * stride + kh], w, b, stride=stride))
+        out.append(torch.cat(bands, 2))
+    return torch.cat(out, 0)
 
 
 def conv2d_transpose_same(x, w_hwoi, b, stride=2):

@@ -24,6 +24,10 @@ CASES = {
     "b4_rel": dict(batch=4, res=2, k=3, disc="thin", losses="rel", dw=1e-2, steps=2, adam_v0=1.0),
     # the north_star PatchGAN extension
     "b2_patch": dict(batch=2, res=2, k=3, disc="patch", losses="wass", dw=1e-2, steps=2, adam_v0=1.0),
+    # BASELINE.json configs[1] at FULL frame size (256x256 -> 512x512, 9 res blocks, 70x70 PatchGAN, CLI loss weights),
+    # batch 2: the inference output (stored sub-sampled 8x8 plus its sums) and the losses of the first step.  Only with
+    # `python make_golden.py c2` (about two minutes of fp64 CPU time).
+    "c2": dict(batch=2, res=9, k=3, disc="patch", losses="wass", dw=1e-5, steps=1, lr=256, sub=8),
 }
 
 
@@ -33,12 +37,13 @@ def frames(seed, n, h, w):
 
 def build(case):
     c = CASES[case]
-    gw = M.init_upscaler_orig((128, 128, 3), c["k"], 64, 2, c["res"], seed=7)
+    hr = 2 * c.get("lr", 64)
+    gw = M.init_upscaler_orig((hr, hr, 3), c["k"], 64, 2, c["res"], seed=7)
     if c["disc"] == "patch":
-        dw = M.init_discriminator_patchgan_70((128, 128, 3), seed=11)
+        dw = M.init_discriminator_patchgan_70((hr, hr, 3), seed=11)
         df = lambda w, x, t: M.discriminator_patchgan_70_forward(w, x, t)
     else:
-        dw = M.init_discriminator_512((128, 128, 3), c["disc"], seed=11)
+        dw = M.init_discriminator_512((hr, hr, 3), c["disc"], seed=11)
         df = lambda w, x, t: M.discriminator_512_forward(w, x, t)
     gf = lambda w, x, t: M.upscaler_orig_forward(w, x, t, c["res"], 2)
     return c, gw, dw, gf, df
@@ -50,15 +55,24 @@ def run(case, dtype=torch.float64):
                       content_loss_weight=1.0, losses=c["losses"], loss_activation="log-sigm",
                       discriminator_loss_weight=c["dw"], adam_v0=c.get("adam_v0", 0.0))
     out = {}
-    lr0 = torch.tensor(frames(100, c["batch"], 64, 64), dtype=dtype)
-    out["predict0"] = orc.predict(lr0).numpy().astype(np.float32)
+    n, sub = c.get("lr", 64), c.get("sub", 1)
+
+    def pack(tag, y):          # full tensor, or (full-size cases) an 8x8 sub-sample plus its sums
+        y = y.numpy()
+        if sub == 1:
+            out[tag] = y.astype(np.float32)
+        else:
+            out[tag + "_sub"] = y[:, ::sub, ::sub].astype(np.float32)
+            out[tag + "_sums"] = np.asarray([y.sum(), np.abs(y).sum(), (y * y).sum()], np.float64)
+    lr0 = torch.tensor(frames(100, c["batch"], n, n), dtype=dtype)
+    pack("predict0", orc.predict(lr0))
     losses = []
     for it in range(c["steps"]):
-        lr = torch.tensor(frames(100 + it, c["batch"], 64, 64), dtype=dtype)
-        hr = torch.tensor(frames(200 + it, c["batch"], 128, 128), dtype=dtype)
+        lr = torch.tensor(frames(100 + it, c["batch"], n, n), dtype=dtype)
+        hr = torch.tensor(frames(200 + it, c["batch"], 2 * n, 2 * n), dtype=dtype)
         losses.append(orc.train_step(lr, hr))
     out["losses"] = np.asarray(losses, np.float64)
-    out["predict_after"] = orc.predict(lr0).numpy().astype(np.float32)
+    pack("predict_after", orc.predict(lr0))
     for tag, w in (("G", orc.g_w), ("D", orc.d_w)):
         names = list(w.keys())
         out[tag + "_sum"] = np.asarray([float(w[k].sum()) for k in names], np.float64)
@@ -67,7 +81,7 @@ def run(case, dtype=torch.float64):
 
 
 if __name__ == "__main__":
-    for case in CASES:
+    for case in (sys.argv[1:] or [c for c in CASES if c != "c2"]):
         res = run(case)
         path = os.path.join(HERE, case + ".npz")
         np.savez_compressed(path, **res)

@@ -447,21 +447,31 @@ def test_bf16_trunk_generator_training_forward_and_gradients(rt, mode):
         e_y = l2(yd, yr)          # relative L2: a value within fp32 rounding of a bf16 rounding boundary lands on the other
         #                           neighbour (one bf16 ulp, 4e-3 of that element) -- a handful of such elements set the max-norm
         gmax = max(float(g.abs().max()) for g in gref.values())
-        worst, worst_plain = 0.0, 0.0
+        worst, worst_plain, worst_ratio = 0.0, 0.0, 0.0
         for k, b in gref.items():
             a = G.ps.grad(k).cpu().double()
-            floor = 1e-4 * gmax * b.numel() ** 0.5        # conv biases in front of a BatchNormalization: (numerically) zero gradient
+            floor = 1e-4 * gmax * b.numel() ** 0.5
+            # tensors whose gradient is (numerically) zero -- conv biases in front of a BatchNormalization -- carry rounding
+            # noise only: they are excluded from the bound (their error is measured against the floor and reported)
+            real = float(b.norm()) >= floor
             e = l2(a, b, floor)
-            worst = max(worst, e)
             worst_plain = max(worst_plain, l2(a, ref["fp32"][2][k], floor))
             if tag == "bf16-trunk":
-                report("    %-40s |g|2=%.2e rel L2 err=%.2e" % (k, float(b.norm()), e))
+                # PER-TENSOR yardstick: this tensor's own distance between the fp32 and fp64 runs of the same emulation
+                e32 = l2(g32[k], b, floor)
+                report("    %-40s |g|2=%.2e rel L2 err=%.2e (oracle fp32-vs-fp64, same storage: %.2e)%s"
+                       % (k, float(b.norm()), e, e32, "" if real else "   [zero gradient: excluded]"))
+                if real:
+                    worst_ratio = max(worst_ratio, e / max(e32, 4e-3))
+                    assert e < max(1e-2, 2.5 * e32), (k, e, e32)
+            if real:
+                worst = max(worst, e)
         out[tag] = (e_y, worst, abs(float(val.item()) - lossr) / lossr)
         if tag == "bf16-trunk":
             e32_y = l2(y32, yr)
-            e32_g = max(l2(g32[k], b, 1e-4 * gmax * b.numel() ** 0.5) for k, b in gref.items())
-            report("    oracle fp32-with-bf16-storage vs oracle fp64-with-bf16-storage: output %.2e, worst gradient tensor %.2e" % (e32_y, e32_g))
-            assert e_y < max(1e-3, 2.5 * e32_y) and worst < max(1e-2, 2.5 * e32_g) and out[tag][2] < 1e-4, (out[tag], e32_y, e32_g)
+            report("    oracle fp32-with-bf16-storage vs oracle fp64-with-bf16-storage: output %.2e; worst product/oracle-fp32 ratio over real gradient tensors %.2f"
+                   % (e32_y, worst_ratio))
+            assert e_y < max(1e-3, 2.5 * e32_y) and out[tag][2] < 1e-4, (out[tag], e32_y)
         report("generator training pass [" + mode + "] (%s) vs oracle with the same storage: output err (rel L2)=%.2e  worst gradient tensor (rel L2)=%.2e  loss err=%.1e"
                "   [vs un-rounded fp64 oracle: output %.2e, gradients %.2e]"
                % ((tag,) + out[tag] + (l2(yd, ref["fp32"][0]), worst_plain)))

@@ -147,7 +147,10 @@ def test_conv_transpose2d(rt, cin, cout, k, n, h, w):
 
 NORM_CASES = [("batch", "prelu", 2, 64, 16, 32, True), ("batch", "none", 3, 64, 7, 9, True),
               ("batch", "lrelu", 2, 128, 8, 8, False), ("instance", "lrelu", 2, 128, 12, 12, False),
-              ("batch", "lrelu", 8, 1024, 1, 1, False), ("batch", "prelu", 1, 64, 64, 64, True)]
+              ("batch", "lrelu", 8, 1024, 1, 1, False), ("batch", "prelu", 1, 64, 64, 64, True),
+              # n*c > 65535 planes: Dense BatchNorm_1 (c = 1024) once D sees >= 64 frames (v1 wiring concatenates real + fake);
+              # the backward kernels walk the planes beyond gridDim.y's limit
+              ("batch", "lrelu", 72, 1024, 1, 1, False), ("batch", "prelu", 130, 512, 2, 2, False)]
 
 
 @pytest.mark.parametrize("norm,act,n,c,h,w,residual", NORM_CASES)
@@ -248,16 +251,20 @@ def test_adam_losses_layout(rt):
     import math
     f32 = lambda v: float(np.float32(v))
     lr_t = f32(1e-3) * math.sqrt(1 - f32(0.999) ** 3) / (1 - f32(0.9) ** 3)          # upscaler.model.Adam.lr_t
-    L.check(lib.vcg_adam_keras_multi(pd.data_ptr(), gd.data_ptr(), md.data_ptr(), vd.data_ptr(), n, lr_t, 0.9, 0.999, 1e-7, rt.stream), "adam")
+    L.check(lib.vcg_adam_keras_multi(pd.data_ptr(), gd.data_ptr(), md.data_ptr(), vd.data_ptr(), n, lr_t, 0.9, 0.999, 1e-7, 1.0, rt.stream), "adam")
     assert max(rel_err(pd, pr), rel_err(md, mr), rel_err(vd, vr)) < 1e-5
     # graph-replayable variant: step count on the device (t = *t_dev + 1), counter incremented by the call
     pd2, gd2, md2, vd2 = (t.float().to(rt.device) for t in (p, gr, m, v))
     t_dev = torch.tensor([2, 0], dtype=torch.int32, device=rt.device)          # {iteration count, lr_t scratch}
     L.check(lib.vcg_adam_keras_multi_dev(pd2.data_ptr(), gd2.data_ptr(), md2.data_ptr(), vd2.data_ptr(), n, 1e-3, 0.9, 0.999, 1e-7,
-                                         t_dev.data_ptr(), rt.stream), "adam_dev")
+                                         1.0, t_dev.data_ptr(), rt.stream), "adam_dev")
     assert int(t_dev[0].item()) == 3
     assert max(rel_err(pd2, pr), rel_err(md2, mr), rel_err(vd2, vr)) < 1e-5
     assert torch.equal(pd2, pd) and torch.equal(md2, md) and torch.equal(vd2, vd)      # lr_t on the device == the host's double
+    # grad_scale: the 1/ranks of a data-parallel SUM bucket folded into the update (g*4 with scale 0.25 == g: exact in binary)
+    pd3, gd3, md3, vd3 = (t.float().to(rt.device) for t in (p, 4 * gr, m, v))
+    L.check(lib.vcg_adam_keras_multi(pd3.data_ptr(), gd3.data_ptr(), md3.data_ptr(), vd3.data_ptr(), n, lr_t, 0.9, 0.999, 1e-7, 0.25, rt.stream), "adam")
+    assert torch.equal(pd3, pd) and torch.equal(md3, md) and torch.equal(vd3, vd)
     # pixel loss
     a, b = torch.randn(2, 3, 17, 19, generator=g, dtype=torch.float64), torch.randn(2, 3, 17, 19, generator=g, dtype=torch.float64)
     for kind, code in (("mse", L.LOSS_MSE), ("mae", L.LOSS_MAE)):
@@ -314,3 +321,66 @@ def test_final_conv_rowchain_tanh(rt):
     e = rel_err(y, yr)
     report("final conv (row-chain kernel) + tanh 256->3 n=2 37x128 fwd=%.2e" % e)
     assert e < TOL
+
+
+HEADS = ["none", "sigmoid", "log-sigm", "tanh", "bi-log"]
+
+
+@pytest.mark.parametrize("kind", HEADS)
+def test_head_activation_fwd_bwd(rt, kind):
+    """discriminator output activations (model.py:885-892): value and derivative against autograd of the oracle's
+    expression, on inputs that include 0, large magnitudes of both signs and the unbounded critic outputs the reference
+    was observed to produce"""
+    from upscaler import _engine as E, _lib as L
+    from oracle import keras_ops as K
+    g = torch.Generator().manual_seed(5)
+    z = torch.cat([torch.randn(997, generator=g, dtype=torch.float64) * 3, torch.tensor([0.0, 1e-6, -1e-6, 20.0, -20.0, 60.0, -60.0, 1e4, -1e4])])
+    if kind == "log-sigm":
+        z = z.clamp(min=-700.0)           # the fp64 oracle's naive log(sigmoid) is finite down to here
+    z = z.float().double().view(-1, 1)
+    zr = z.clone().requires_grad_(True)
+    yr = K.head_activation(zr, kind)
+    dy = torch.randn(*z.shape, generator=g, dtype=torch.float64)
+    (yr * dy).sum().backward()
+    zd = z.float().to(rt.device)
+    y = E.head_act_fwd(rt, zd, L.HEAD_KINDS[kind])
+    dz = E.head_act_bwd(rt, zd, dy.float().to(rt.device), L.HEAD_KINDS[kind])
+    # element-wise relative error (values span many orders of magnitude)
+    ev = float(((y.cpu().double() - yr.detach()).abs() / (yr.detach().abs() + 1e-6)).max())
+    ed = float(((dz.cpu().double() - zr.grad).abs() / (zr.grad.abs() + 1e-6)).max())
+    report("head activation %-8s value err=%.2e derivative err=%.2e" % (kind, ev, ed))
+    assert ev < 1e-5 and ed < 1e-5
+
+
+@pytest.mark.parametrize("loss_act", HEADS)
+@pytest.mark.parametrize("head", HEADS)
+def test_gan_loss_all_activation_pairs(rt, head, loss_act):
+    """D head activation x GanLosses.loss_activation, all 25 pairs (train_gan3.py:58,63): the relativistic discriminator
+    and generator losses act(mean(D_a) - mean(D_b)) and their gradients wrt the critic's PRE-activation outputs, evaluated
+    entirely on the device (vcg_head_act_* + vcg_mean_reduce + vcg_gan_loss), against autograd of model.py:244-259."""
+    from upscaler import _engine as E, _lib as L
+    from oracle import keras_ops as K
+    g = torch.Generator().manual_seed(HEADS.index(head) * 7 + HEADS.index(loss_act))
+    za = (torch.randn(6, 1, generator=g, dtype=torch.float64) * 2 + 0.3).float().double()
+    zb = (torch.randn(6, 1, generator=g, dtype=torch.float64) * 2 - 0.2).float().double()
+    zar, zbr = za.clone().requires_grad_(True), zb.clone().requires_grad_(True)
+    loss = K.head_activation(K.head_activation(zar, head).mean() - K.head_activation(zbr, head).mean(), loss_act)
+    loss.backward()
+    hk, lk = L.HEAD_KINDS[head], L.HEAD_KINDS[loss_act]
+    zad, zbd = za.float().to(rt.device), zb.float().to(rt.device)
+    means, out = rt.zeros(2), rt.zeros(1)
+    E.mean_scalar(rt, E.head_act_fwd(rt, zad, hk), out=means[0:1])
+    E.mean_scalar(rt, E.head_act_fwd(rt, zbd, hk), out=means[1:2])
+    da, db = rt.empty(6, 1), rt.empty(6, 1)
+    E.gan_loss(rt, means[0:1], means[1:2], 1.0, lk, out, da, 1.0 / 6, db, -1.0 / 6)
+    dza, dzb = E.head_act_bwd(rt, zad, da, hk), E.head_act_bwd(rt, zbd, db, hk)
+    ev = abs(float(out.item()) - float(loss)) / (abs(float(loss)) + 1e-6)
+    eg = max(rel_err(dza, zar.grad), rel_err(dzb, zbr.grad))
+    report("gan loss head=%-8s loss_activation=%-8s value err=%.2e grad err=%.2e" % (head, loss_act, ev, eg))
+    assert ev < 1e-5 and eg < 1e-5
+    # summed means of 2 "ranks" with mean_scale 1/2 (the data-parallel form) give the same loss
+    means2 = rt.zeros(2)
+    E.axpby(rt, means, means2, 2.0, 0.0)
+    out2 = rt.zeros(1)
+    E.gan_loss(rt, means2[0:1], means2[1:2], 0.5, lk, out2, da, 1.0 / 6, db, -1.0 / 6)
+    assert torch.equal(out2, out)

@@ -36,28 +36,28 @@ def _perturb(w, seed):
     return out
 
 
-def _oracle_pair(kernel_size, res, disc, dtype=torch.float64):
+def _oracle_pair(kernel_size, res, disc, dtype=torch.float64, d_act="none"):
     from oracle import models as M
     gw = _perturb(M.init_upscaler_orig((128, 128, 3), kernel_size, 64, 2, res, seed=7), 1)
     if disc == "patch":
         dw = _perturb(M.init_discriminator_patchgan_70((128, 128, 3), seed=11), 2)
-        df = lambda w, x, t: M.discriminator_patchgan_70_forward(w, x, t)
+        df = lambda w, x, t: M.discriminator_patchgan_70_forward(w, x, t, activation=d_act)
     else:
         dw = _perturb(M.init_discriminator_512((128, 128, 3), disc, seed=11), 2)
-        df = lambda w, x, t: M.discriminator_512_forward(w, x, t)
+        df = lambda w, x, t: M.discriminator_512_forward(w, x, t, activation=d_act)
     gf = lambda w, x, t: M.upscaler_orig_forward(w, x, t, res, 2)
     return gw, dw, gf, df
 
 
-def _product_pair(kernel_size, res, disc, gw, dw):
+def _product_pair(kernel_size, res, disc, gw, dw, d_act="none"):
     from upscaler import model as PM
     G = PM.make_upscaler_orig((128, 128, 3), kernel_size=kernel_size, upscale_factor=2, res_block_num=res)
     if disc == "patch":
-        D = PM.make_discriminator_patchgan_70((128, 128, 3))
+        D = PM.make_discriminator_patchgan_70((128, 128, 3), d_act)
     elif disc == "simple":
-        D = PM.make_discriminator_simple_512((128, 128, 3))
+        D = PM.make_discriminator_simple_512((128, 128, 3), d_act)
     else:
-        D = PM.make_discriminator_thin_512((128, 128, 3))
+        D = PM.make_discriminator_thin_512((128, 128, 3), d_act)
     G.set_weights_dict(gw)
     D.set_weights_dict(dw)
     return G, D
@@ -150,24 +150,29 @@ def test_generator_layers_ragged_shapes(rt, shape):
         assert worst < TOL and e < TOL
 
 
-CASES = [("gan2", "wass", "simple", 3), ("gan2", "rel", "thin", 3), ("v1", "wass", "simple", 3), ("gan2", "wass", "patch", 3),
-         ("gan2", "wass", "simple", 5)]
+# (wiring, losses, discriminator, kernel_size, D output activation, loss activation).  The fifth case is the reference's
+# default gan2 configuration: -dm s512 -da bi-log -dl rel -dla log-sigm (train_gan3.py:57-58,62-63,258,274-277)
+CASES = [("gan2", "wass", "simple", 3, "none", "log-sigm"), ("gan2", "rel", "thin", 3, "none", "log-sigm"),
+         ("v1", "wass", "simple", 3, "none", "log-sigm"), ("gan2", "wass", "patch", 3, "none", "log-sigm"),
+         ("gan2", "wass", "simple", 5, "none", "log-sigm"), ("gan2", "rel", "simple", 3, "bi-log", "log-sigm"),
+         ("gan2", "rel", "patch", 3, "tanh", "sigmoid"), ("gan2", "wass", "thin", 3, "sigmoid", "log-sigm"),
+         ("gan2", "rel", "thin", 3, "log-sigm", "bi-log"), ("gan2", "rel", "simple", 3, "none", "tanh")]
 ADAM_V0 = 1.0
 
 
-def _build_pair(rt, wiring, losses, disc, k, adam_v0, res=2, dwt=1e-2):
+def _build_pair(rt, wiring, losses, disc, k, adam_v0, res=2, dwt=1e-2, d_act="none", l_act="log-sigm"):
     from oracle import models as M, train as T
     from upscaler import model as PM, _lib as L
-    gw, dw, gf, df = _oracle_pair(k, res, disc)
-    G, D = _product_pair(k, res, disc, gw, dw)
+    gw, dw, gf, df = _oracle_pair(k, res, disc, d_act=d_act)
+    G, D = _product_pair(k, res, disc, gw, dw, d_act)
 
     def mk(dtype):
         return T.GanOracle(gf, M.to_torch(gw, dtype), df, M.to_torch(dw, dtype), wiring=wiring, content="mse",
-                           content_loss_weight=1.0, losses=losses, loss_activation="log-sigm", discriminator_loss_weight=dwt,
+                           content_loss_weight=1.0, losses=losses, loss_activation=l_act, discriminator_loss_weight=dwt,
                            adam_v0=adam_v0)
     opt = PM.Adam()
     if wiring == "gan2":
-        fac = (lambda: PM.WassersteinLosses()) if losses == "wass" else (lambda: PM.RelativisticLosses(loss_activation="log-sigm"))
+        fac = (lambda: PM.WassersteinLosses()) if losses == "wass" else (lambda: PM.RelativisticLosses(loss_activation=l_act))
         models = PM.make_and_compile_gan2(G, D, (64, 64, 3), (128, 128, 3), "mse", 1.0, fac, dwt, optimizer=opt)
     else:
         models = PM.make_and_compile_gan(G, D, (64, 64, 3), (128, 128, 3), "mse", 1.0, PM.wasserstein_loss, dwt, optimizer=opt)
@@ -191,8 +196,8 @@ def _loop_body(wiring, models, lr, hr, bs):
     return (loss_disc,) + tuple(loss_gan)
 
 
-@pytest.mark.parametrize("wiring,losses,disc,k", CASES)
-def test_train_step_parity(rt, wiring, losses, disc, k):
+@pytest.mark.parametrize("wiring,losses,disc,k,d_act,l_act", CASES)
+def test_train_step_parity(rt, wiring, losses, disc, k, d_act, l_act):
     """Two loop-body iterations against the fp64 oracle: the four reported losses of both iterations, every
     weight of G and D after the two Adam updates each, the BN moving statistics and the networks as functions.
 
@@ -202,10 +207,10 @@ def test_train_step_parity(rt, wiring, losses, disc, k):
     -- for the product and for an fp32 run of the oracle alike (test_train_step_default_adam_vs_fp32_oracle
     shows that).  Primed, the update is smooth in the gradient and parity is meaningful at 1e-3."""
     bs = 4
-    G, D, df, models, opt, mk = _build_pair(rt, wiring, losses, disc, k, ADAM_V0)
+    G, D, df, models, opt, mk = _build_pair(rt, wiring, losses, disc, k, ADAM_V0, d_act=d_act, l_act=l_act)
     orc, orc32 = mk(torch.float64), mk(torch.float32)
     g0, d0 = G.get_weights_dict(), D.get_weights_dict()
-    tag = "%s/%s/%s/k%d" % (wiring, losses, disc, k)
+    tag = "%s/%s(%s)/%s(%s)/k%d" % (wiring, losses, l_act, disc, d_act, k)
     for it in range(2):
         lr, hr = _frames(10 + it, bs, 64, 64), _frames(20 + it, bs, 128, 128)
         got = _loop_body(wiring, models, lr, hr, bs)
@@ -316,15 +321,18 @@ def test_generator_gradients_direct(rt):
     assert abs(val.item() - loss.item()) / loss.item() < 1e-4
 
 
-def test_graph_replay_matches_eager(rt):
+@pytest.mark.parametrize("losses,disc,d_act", [("wass", "patch", "none"), ("rel", "simple", "bi-log")])
+def test_graph_replay_matches_eager(rt, losses, disc, d_act):
     """hipGraph capture of the loop body: replays must reproduce the eager three-call step bit for bit
-    (same kernels, same order, deterministic reductions), including the device-side Adam step counter."""
+    (same kernels, same order, deterministic reductions), including the device-side Adam step counter -- also for the
+    reference's default configuration (relativistic log-sigm loss on a bi-log critic, train_gan3.py:58,62-63), whose
+    loss non-linearity is evaluated on the device."""
     from upscaler import _engine as E
-    bs = 2
+    bs = 2 if losses == "wass" else 4
     frames = [(_frames(30 + i, bs, 64, 64), _frames(40 + i, bs, 128, 128)) for i in range(4)]
 
     def run(graph):
-        G, D, df, models, opt, mk = _build_pair(rt, "gan2", "wass", "patch", 3, 0.0)
+        G, D, df, models, opt, mk = _build_pair(rt, "gan2", losses, disc, 3, 0.0, d_act=d_act)
         tr = models[2].trainer
         dev = [(E.to_device_nchw(rt, a), E.to_device_nchw(rt, b)) for a, b in frames]
         out = []
@@ -407,3 +415,113 @@ def test_trainer_state_roundtrip_resumes_bit_exactly(rt, tmp_path):
     assert a == b
     assert torch.equal(G1.ps.params, G2.ps.params) and torch.equal(D1.ps.params, D2.ps.params)
     assert torch.equal(t1.g_slots.v, t2.g_slots.v) and torch.equal(t1.d_slots.m, t2.d_slots.m)
+
+
+def _small_trainer(losses="wass"):
+    from upscaler import model as PM
+    G = PM.make_upscaler_orig((64, 64, 3), kernel_size=3, upscale_factor=2, res_block_num=1, seed=7)
+    D = PM.make_discriminator_patchgan_70((64, 64, 3), seed=11)
+    fac = (lambda: PM.WassersteinLosses()) if losses == "wass" else (lambda: PM.RelativisticLosses())
+    _, _, gan = PM.make_and_compile_gan2(G, D, (32, 32, 3), (64, 64, 3), "mse", 1.0, fac, 1e-2, optimizer=PM.Adam())
+    return G, D, gan.trainer
+
+
+def test_graph_replay_survives_workspace_growth(rt):
+    """a recorded step has the shared scratch buffer's address baked into its kernels; a later, larger eager request
+    (e.g. G.predict on full frames while training on crops) must not free that buffer under the graph"""
+    from upscaler import _engine as E, model as PM
+    lr = [E.to_device_nchw(rt, _frames(50 + i, 2, 32, 32)) for i in range(3)]
+    hr = [E.to_device_nchw(rt, _frames(60 + i, 2, 64, 64)) for i in range(3)]
+
+    def run(grow):
+        G, D, tr = _small_trainer()
+        tr.capture_train_step(lr[0], hr[0])
+        out = [tr.train_step_graph(lr[1], hr[1])]
+        if grow:
+            ws0 = rt._ws
+            rt.workspace(8 * rt._ws.numel())                # what a bigger model / frame would ask for
+            assert rt._ws is not ws0 and any(w is ws0 for w in rt._ws_retired)
+            junk = [torch.full((ws0.numel() // 4,), float("nan"), device=rt.device) for _ in range(3)]   # would land in freed memory
+        out.append(tr.train_step_graph(lr[2], hr[2]))
+        return out, G.ps.params.clone(), D.ps.params.clone()
+
+    a, b = run(False), run(True)
+    assert a[0] == b[0] and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    assert all(np.isfinite(v) for step in b[0] for v in step)
+
+
+def test_graph_replay_after_load_state_uses_new_weights(rt, tmp_path):
+    """weights replaced from outside while a recorded step exists: the next replay must derive its per-tap transposed
+    kernels from the NEW weights (their derivation is part of the recording), bit-identical to the eager step"""
+    from upscaler import _engine as E
+    lr = [E.to_device_nchw(rt, _frames(70 + i, 2, 32, 32)) for i in range(3)]
+    hr = [E.to_device_nchw(rt, _frames(80 + i, 2, 64, 64)) for i in range(3)]
+    # a state three steps ahead, from an independent eager run
+    G0, D0, t0 = _small_trainer()
+    t0._t_dev = torch.tensor([0, 0], dtype=torch.int32, device=rt.device)
+    for i in range(3):
+        t0.train_step(lr[i], hr[i])
+    path = str(tmp_path / "state.safetensors")
+    t0.save_state(path)
+    ref = t0.train_step(lr[0], hr[0])
+    # a trainer that recorded its step on its initial weights, then loads that state and replays
+    G1, D1, t1 = _small_trainer()
+    t1.capture_train_step(lr[0], hr[0])
+    t1.load_state(path)
+    got = t1.train_step_graph(lr[0], hr[0])
+    assert got == ref, (got, ref)
+    assert torch.equal(G1.ps.params, G0.ps.params) and torch.equal(D1.ps.params, D0.ps.params)
+
+
+def test_v1_gan_targets_are_validated(rt):
+    from upscaler import model as PM
+    G = PM.make_upscaler_orig((64, 64, 3), kernel_size=3, upscale_factor=2, res_block_num=1, seed=7)
+    D = PM.make_discriminator_patchgan_70((64, 64, 3), seed=11)
+    _, _, gan = PM.make_and_compile_gan(G, D, (32, 32, 3), (64, 64, 3), "mse", 1.0, PM.wasserstein_loss, 1e-2, optimizer=PM.Adam())
+    lr, hr = _frames(1, 2, 32, 32), _frames(2, 2, 64, 64)
+    assert len(gan.train_on_batch(lr, [hr, np.ones(2)])) == 3
+    with pytest.raises(NotImplementedError):
+        gan.train_on_batch(lr, [hr, -np.ones(2)])
+
+
+def test_reference_default_generator_x4_16blocks_k5(rt):
+    """make_upscaler_orig with the reference's own defaults -- kernel_size=5, upscale_factor=4, res_block_num=16
+    (model.py:267) -- end to end: two stacked upsampling_blocks (64 -> 256 -> 256 channels, model.py:287-288), 5x5
+    residual convolutions.  Inference and training-mode forward plus every gradient tensor against the fp64 oracle."""
+    from oracle import models as M
+    from upscaler import _engine as E, _lib as L, model as PM
+    out_shape, res, k, f = (96, 128, 3), 16, 5, 4
+    gw = _perturb(M.init_upscaler_orig(out_shape, k, 64, f, res, seed=7), 3)
+    G = PM.make_upscaler_orig(out_shape)                    # all defaults
+    assert (G.upscale_times, len(G.blocks), G.blocks[0][0].k, G.ups[1].cin, G.ups[1].cout) == (2, 16, 5, 256, 256)
+    assert G.count_params() == M.count_params(gw)
+    assert G.input_shape == (None, 24, 32, 3) and G.output_shape == (None, 96, 128, 3)
+    G.set_weights_dict(gw)
+    x, t = _frames(11, 2, 24, 32), _frames(12, 2, 96, 128)
+    gf = lambda w, xx, tr: M.upscaler_orig_forward(w, xx, tr, res, f)
+    with torch.no_grad():
+        y0, _ = gf(M.to_torch(gw, torch.float64), torch.tensor(x, dtype=torch.float64), False)
+    e0 = rel_err(torch.tensor(G.predict(x)), y0)
+    leaf = M.to_torch(gw, torch.float64, requires_grad=True)
+    y, _ = gf(leaf, torch.tensor(x, dtype=torch.float64), True)
+    loss = ((y - torch.tensor(t, dtype=torch.float64)) ** 2).mean()
+    names = [n for n, v in leaf.items() if v.requires_grad]
+    grads = dict(zip(names, torch.autograd.grad(loss, [leaf[n] for n in names])))
+    leaf32 = M.to_torch(gw, torch.float32, requires_grad=True)
+    y32, _ = gf(leaf32, torch.tensor(x), True)
+    g32 = dict(zip(names, torch.autograd.grad(((y32 - torch.tensor(t)) ** 2).mean(), [leaf32[n] for n in names])))
+    yd, tape = G.forward(E.to_device_nchw(rt, x), True)
+    e1 = rel_err(E.to_nhwc(rt, yd), y)
+    val, dy = PM._pixel_loss(rt, yd, E.to_device_nchw(rt, t), "mse", 1.0)
+    G.backward(tape, dy, 0)
+    gmax = max(float(g.abs().max()) for g in grads.values())
+    worst = 0.0
+    for n in names:
+        a, b = G.ps.grad(n).cpu().double(), grads[n]
+        err = float((a - b).abs().max() / (b.abs().max() + 1e-4 * gmax))
+        e32 = float((g32[n].double() - b).abs().max() / (b.abs().max() + 1e-4 * gmax))
+        worst = max(worst, err)
+        assert err < max(TOL, 4 * e32), (n, err, e32)         # activation-mask flips: see test_generator_gradients_direct
+    report("reference-default generator (k5, x4, 16 blocks) predict err=%.2e train fwd err=%.2e worst gradient err=%.2e" % (e0, e1, worst))
+    assert e0 < TOL and e1 < TOL
+    assert abs(val.item() - loss.item()) / loss.item() < 1e-4

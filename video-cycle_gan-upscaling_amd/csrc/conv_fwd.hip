@@ -131,44 +131,41 @@ __global__ __launch_bounds__(256, (KH >= 9 ? 1 : 2)) void conv_fwd_kernel(const 
 
     float rin[C::IN_PT], rw[C::W_PT];
 
-    // per-thread input offsets inside one image's [cin][h][w] block, computed once (-1 = zero padding);
-    // a chunk only adds a wave-uniform channel offset, so the staging loop costs ~2 VALU per element
-    int in_off[C::IN_PT];
+    // per-thread input BYTE offsets inside a chunk's [CK][h][w] block, computed once (VCG_OOB = zero padding); a chunk
+    // only moves the descriptor's base (scalar), whose record count also cuts off the channels past cin: the
+    // staging loop is one buffer_load per element, no per-element VALU and nothing that depends on the loaded data
+    unsigned in_off[C::IN_PT];
 #pragma unroll
     for (int i = 0; i < C::IN_PT; ++i) {
         const int e = tid + i * 256;
-        int off = -1;
+        unsigned off = VCG_OOB;
         if (e < C::IN_ELEMS) {
             const int ci = e / C::PLANE, rem = e % C::PLANE;
             const int r = rem / C::IW, c = rem % C::IW;
             const int gy = gy0 + r, gx = gx0 + c;
-            if (gy >= 0 && gy < p.h && gx >= 0 && gx < p.w_) off = (ci * p.h + gy) * p.w_ + gx;
+            if (gy >= 0 && gy < p.h && gx >= 0 && gx < p.w_) off = 4u * (unsigned)((ci * p.h + gy) * p.w_ + gx);
         }
         in_off[i] = off;
     }
     const int hw = p.h * p.w_;
-    const bool m_ok = co0 + lane < p.cout;
+    // weights: row q = (ci, tap) of the chunk is wave-uniform, the lane is the output channel.  Rows of channels past
+    // cin alias the next tap's rows (finite values that meet zero inputs) or fall off the tensor's end (range check -> 0);
+    // lanes past cout read the last valid column: their output rows are never stored
+    const int wvu = __builtin_amdgcn_readfirstlane(wv);
+    const unsigned wcol = 4u * (unsigned)(co0 + lane < p.cout ? co0 + lane : p.cout - 1);
+    const size_t wbytes = (size_t)C::T * p.cin * p.cout * sizeof(float);
 
     auto load_chunk = [&](int ci0) {
-        const float* xc = xn + (size_t)ci0 * hw;
-        const unsigned lim = (unsigned)((p.cin - ci0) * hw);    // channels >= cin read as zero
-        // every load is unconditional from a clamped (always valid) address and masked afterwards: a
-        // conditional load makes hipcc branch around it and drain vmcnt per element
+        const vcg_rsrc rx = make_rsrc(xn + (size_t)ci0 * hw, (size_t)(p.cin - ci0) * hw * sizeof(float));
 #pragma unroll
-        for (int i = 0; i < C::IN_PT; ++i) {
-            const bool ok = (unsigned)in_off[i] < lim;
-            const float v = xc[ok ? in_off[i] : 0];
-            rin[i] = ok ? v : 0.f;
-        }
-        // weights: element e = tid + 256 i  ->  row q = (ci, tap), m = lane
+        for (int i = 0; i < C::IN_PT; ++i) rin[i] = buf_load(rx, in_off[i]);
+        const vcg_rsrc rwt = make_rsrc(p.w + (size_t)ci0 * p.cout, wbytes - (size_t)ci0 * p.cout * sizeof(float));
 #pragma unroll
         for (int i = 0; i < C::W_PT; ++i) {
-            const int q = wv + 4 * i;
+            const int q = wvu + 4 * i;
             const int t = q % C::T, ci = q / C::T;
-            const int ch = ci0 + ci, tap = p.flip ? (C::T - 1 - t) : t;
-            const bool ok = ch < p.cin && m_ok;
-            const float v = p.w[ok ? (tap * p.cin + ch) * p.cout + co0 + lane : 0];
-            rw[i] = ok ? v : 0.f;
+            const int tap = p.flip ? (C::T - 1 - t) : t;
+            rw[i] = buf_load(rwt, 4u * (unsigned)((tap * p.cin + ci) * p.cout) + wcol);
         }
     };
     auto store_chunk = [&]() {
@@ -379,6 +376,9 @@ __global__ __launch_bounds__(256) void conv_smallm_kernel(const ConvParams p) {
     const bool col_ok = gx >= 0 && gx < p.w_;
     const int gxc = min(max(gx, 0), p.w_ - 1);
     const int hw = p.h * p.w_;
+    // range-checked buffer loads: padding / missing channels get the offset VCG_OOB and read as 0 (vcg_common.hpp)
+    const vcg_rsrc rx = make_rsrc(xn, (size_t)p.cin * hw * sizeof(float));
+    const vcg_rsrc rwt = make_rsrc(p.w, (size_t)KH * KW * p.cin * p.cout * sizeof(float));
     auto load_chunk = [&](int ci0) {
 #pragma unroll
         for (int i = 0; i < C::IN_PT; ++i) {
@@ -386,26 +386,19 @@ __global__ __launch_bounds__(256) void conv_smallm_kernel(const ConvParams p) {
             const int r = q % C::IH, ci = q / C::IH;
             const int gy = gy0 + r, ch = ci0 + ci;
             const bool ok = col_ok && ch < p.cin && gy >= 0 && gy < p.h;
-            const int chc = min(ch, p.cin - 1), gyc = min(max(gy, 0), p.h - 1);      // scalar clamps
-            const float v = xn[(size_t)chc * hw + gyc * p.w_ + gxc];
-            rin[i] = ok ? v : 0.f;
+            rin[i] = buf_load(rx, ok ? 4u * (unsigned)(ch * hw + gy * p.w_ + gxc) : VCG_OOB);
         }
 #pragma unroll
         for (int i = 0; i < C::W_PT; ++i) {
             const int e = tid + i * 256;
-            float v = 0.f;
-            if (e < C::W_ELEMS) {
-                const int mi = e & 31, q = e >> 5;
-                const int ky = q % KH, ci = q / KH;
-                const int ch = ci0 + ci;
-                const bool ok = ch < p.cin && mi < mrows;
-                const int mch = mi / KW, kx = mi % KW;
-                int tap = ky * KW + kx;
-                if (p.flip) tap = KH * KW - 1 - tap;
-                const float wv_ = p.w[ok ? tap * p.ws_t + mch * p.ws_m + ch * p.ws_k : 0];
-                v = ok ? wv_ : 0.f;
-            }
-            rw[i] = v;
+            const int mi = e & 31, q = e >> 5;
+            const int ky = q % KH, ci = q / KH;
+            const int ch = ci0 + ci;
+            const bool ok = e < C::W_ELEMS && ch < p.cin && mi < mrows;
+            const int mch = mi / KW, kx = mi % KW;
+            int tap = ky * KW + kx;
+            if (p.flip) tap = KH * KW - 1 - tap;
+            rw[i] = buf_load(rwt, ok ? 4u * (unsigned)(tap * p.ws_t + mch * p.ws_m + ch * p.ws_k) : VCG_OOB);
         }
     };
     auto store_chunk = [&]() {

@@ -70,40 +70,41 @@ __global__ __launch_bounds__(256, (MT == 1 ? 2 : 1)) void convt_kernel(const Con
     const float* xn = p.x + (size_t)n * p.cin * p.h * p.w_;
 
     float rin[C::IN_PT], rw[C::W_PT];
-    int in_off[C::IN_PT];   // offsets inside one image, computed once (-1 = zero padding)
+    // byte offsets inside a chunk's [CK][h][w] block, computed once (VCG_OOB = zero padding); staging loads go through
+    // range-checked buffer descriptors whose base moves with the chunk (vcg_common.hpp): no mask behind a load
+    unsigned in_off[C::IN_PT];
 #pragma unroll
     for (int i = 0; i < C::IN_PT; ++i) {
         const int e = tid + i * 256;
-        int off = -1;
+        unsigned off = VCG_OOB;
         if (e < C::IN_ELEMS) {
             const int ci = e / C::PLANE, rem = e % C::PLANE;
             const int r = rem / C::NC, c = rem % C::NC;
             const int gy = gy0 + r, gx = gx0 + c;
-            if (gy >= 0 && gy < p.h && gx >= 0 && gx < p.w_) off = (ci * p.h + gy) * p.w_ + gx;
+            if (gy >= 0 && gy < p.h && gx >= 0 && gx < p.w_) off = 4u * (unsigned)((ci * p.h + gy) * p.w_ + gx);
         }
         in_off[i] = off;
     }
     const int hw = p.h * p.w_;
+    // weight element e -> row q = (ci, tap), column m; rows of channels past cin alias later rows (finite, meet zero
+    // inputs) or fall off the end (-> 0); columns past cout are never stored
+    unsigned w_off[C::W_PT];
+#pragma unroll
+    for (int i = 0; i < C::W_PT; ++i) {
+        const int e = tid + i * 256;
+        const int m = e % C::MB, q = e / C::MB;
+        const int t = q % C::T, ci = q / C::T;
+        const int col = co0 + m < p.cout ? co0 + m : p.cout - 1;
+        w_off[i] = e < C::W_ELEMS ? 4u * (unsigned)((t * p.cin + ci) * p.cout + col) : VCG_OOB;
+    }
+    const size_t wbytes = (size_t)C::T * p.cin * p.cout * sizeof(float);
     auto load_chunk = [&](int ci0) {
-        const float* xc = xn + (size_t)ci0 * hw;
-        const unsigned lim = (unsigned)((p.cin - ci0) * hw);
-        // unconditional loads from clamped addresses, masked afterwards (no per-element branches)
+        const vcg_rsrc rx = make_rsrc(xn + (size_t)ci0 * hw, (size_t)(p.cin - ci0) * hw * sizeof(float));
 #pragma unroll
-        for (int i = 0; i < C::IN_PT; ++i) {
-            const bool ok = (unsigned)in_off[i] < lim;
-            const float v = xc[ok ? in_off[i] : 0];
-            rin[i] = ok ? v : 0.f;
-        }
+        for (int i = 0; i < C::IN_PT; ++i) rin[i] = buf_load(rx, in_off[i]);
+        const vcg_rsrc rwt = make_rsrc(p.w + (size_t)ci0 * p.cout, wbytes - (size_t)ci0 * p.cout * sizeof(float));
 #pragma unroll
-        for (int i = 0; i < C::W_PT; ++i) {
-            const int e = tid + i * 256;
-            const int m = e % C::MB, q = e / C::MB;      // row q = (ci, tap), column m
-            const int t = q % C::T, ci = q / C::T;
-            const int ch = ci0 + ci;
-            const bool ok = e < C::W_ELEMS && ch < p.cin && co0 + m < p.cout;
-            const float v = p.w[ok ? (t * p.cin + ch) * p.cout + co0 + m : 0];
-            rw[i] = ok ? v : 0.f;
-        }
+        for (int i = 0; i < C::W_PT; ++i) rw[i] = buf_load(rwt, w_off[i]);
     };
     auto store_chunk = [&]() {
 #pragma unroll

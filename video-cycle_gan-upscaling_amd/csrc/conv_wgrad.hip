@@ -123,18 +123,18 @@ __global__ __launch_bounds__(64 * NW, (MW * NJ * 16 > 100 ? 1 : 2)) void wgrad_k
         const int ty = q % p.tiles_y; q /= p.tiles_y;
         const int n = q;
         const int ax0 = tx * 32, ay0 = ty * TH;
-        const float* An = p.A + (size_t)n * p.mtot * p.ah * p.aw;
-        // unconditional loads from clamped addresses, masked afterwards (no per-element branches)
+        // range-checked buffer loads (vcg_common.hpp): the validity select sits on the ADDRESS, nothing depends on the
+        // loaded data until store_tile -- the prefetch really flies under the MFMA loop
+        const vcg_rsrc rA = make_rsrc(p.A + (size_t)n * p.mtot * p.ah * p.aw, (size_t)p.mtot * p.ah * p.aw * sizeof(float));
 #pragma unroll
         for (int i = 0; i < C::A_PT; ++i) {
             const int e = tid + i * C::NT;
             const int c = e & 31, r = (e >> 5) % TH, m = e / (32 * TH);
             const int ay = ay0 + r, ax = ax0 + c;
             const bool ok = e < C::A_ELEMS && m0 + m < p.mtot && ay < p.ah && ax < p.aw;
-            const float v = An[ok ? ((m0 + m) * p.ah + ay) * p.aw + ax : 0];
-            ra[i] = ok ? v : 0.f;
+            ra[i] = buf_load(rA, ok ? 4u * (unsigned)(((m0 + m) * p.ah + ay) * p.aw + ax) : VCG_OOB);
         }
-        const float* Bn = p.B + ((size_t)n * p.jctot + jc0) * p.bh * p.bw;
+        const vcg_rsrc rB = make_rsrc(p.B + ((size_t)n * p.jctot + jc0) * p.bh * p.bw, (size_t)(p.jctot - jc0) * p.bh * p.bw * sizeof(float));
         const int by0 = ay0 * S - p.pt, bx0 = ax0 * S - p.pl;
         const int c32 = tid & 31, rg = tid >> 5;
 #pragma unroll
@@ -148,8 +148,7 @@ __global__ __launch_bounds__(64 * NW, (MW * NJ * 16 > 100 ? 1 : 2)) void wgrad_k
             for (int q = 0; q < C::QSEG; ++q) {
                 const int bx = bx0 + q * 32 + c32;
                 const bool ok = rok && bx >= 0 && bx < p.bw;
-                const float v = Bn[ok ? rbase + q * 32 + c32 : 0];
-                rb[i * C::QSEG + q] = ok ? v : 0.f;
+                rb[i * C::QSEG + q] = buf_load(rB, ok ? 4u * (unsigned)(rbase + q * 32 + c32) : VCG_OOB);
             }
         }
 #pragma unroll
@@ -159,8 +158,7 @@ __global__ __launch_bounds__(64 * NW, (MW * NJ * 16 > 100 ? 1 : 2)) void wgrad_k
             const int jc = row / C::BH, r = row % C::BH;
             const int by = by0 + r, bx = bx0 + c;
             const bool ok = row < C::ROWS && jc < jc_here && by >= 0 && by < p.bh && bx >= 0 && bx < p.bw;
-            const float v = Bn[ok ? (jc * p.bh + by) * p.bw + bx : 0];
-            rb[C::RPT * C::QSEG + i] = ok ? v : 0.f;
+            rb[C::RPT * C::QSEG + i] = buf_load(rB, ok ? 4u * (unsigned)((jc * p.bh + by) * p.bw + bx) : VCG_OOB);
         }
     };
     auto store_tile = [&]() {

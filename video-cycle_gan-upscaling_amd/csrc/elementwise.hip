@@ -28,7 +28,9 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float* saved, const 
                                                       int act, float act_alpha, const float* prelu, float* dx,
                                                       float* part_alpha, float* part_sum /* [n*c][gridDim.x] or null */) {
     __shared__ float red[8];
-    const int plane = blockIdx.y;
+    // planes beyond the 65535 limit of gridDim.y are walked by the same block (Dense BatchNormalization with
+    // 1024 channels and >= 64 frames: n*c > 65535)
+    for (int plane = blockIdx.y; plane < n * c; plane += gridDim.y) {
     const int ch = plane % c;
     const float al = (act == VCG_ACT_PRELU) ? prelu[ch] : act_alpha;
     const size_t base = (size_t)plane * hw;
@@ -58,6 +60,7 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float* saved, const 
             if (part_alpha) part_alpha[(size_t)plane * gridDim.x + blockIdx.x] = v[0];
             if (part_sum) part_sum[(size_t)plane * gridDim.x + blockIdx.x] = v[1];
         }
+    }
     }
 }
 
@@ -151,10 +154,10 @@ __global__ void axpby_kernel(const float* x, float* y, size_t count, float a, fl
 
 // ---- Keras-form Adam over a flat buffer ---------------------------------------------------------------
 __global__ __launch_bounds__(256) void adam_kernel(float* p, const float* g, float* m, float* v, size_t count,
-                                                   float lr_t, float b1, float b2, float eps) {
+                                                   float lr_t, float b1, float b2, float eps, float gscale) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= count) return;
-    const float gi = g[i];
+    const float gi = g[i] * gscale;
     const float mi = b1 * m[i] + (1.f - b1) * gi;
     const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
     m[i] = mi;
@@ -175,11 +178,11 @@ __global__ void adam_lr_kernel(int* t_dev, float lr, float b1, float b2) {
 }
 
 __global__ __launch_bounds__(256) void adam_dev_kernel(float* p, const float* g, float* m, float* v, size_t count, float b1,
-                                                       float b2, float eps, const int* t_dev) {
+                                                       float b2, float eps, float gscale, const int* t_dev) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= count) return;
     const float lr_t = ((const float*)t_dev)[1];
-    const float gi = g[i];
+    const float gi = g[i] * gscale;
     const float mi = b1 * m[i] + (1.f - b1) * gi;
     const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
     m[i] = mi;
@@ -288,6 +291,58 @@ __global__ __launch_bounds__(256) void kernel_transpose_kernel(const float* src,
         if (b0 + r < b && a0 + tx < a) d[(size_t)(b0 + r) * a + a0 + tx] = tile[tx][r];
 }
 
+
+// ---- discriminator output squashing (model.py:885-892) and GanLosses.loss_activation (model.py:172-181) -----------
+// sigmoid / log(sigmoid) / tanh / bi-log: x/(1+|x|) * log(|x|+2).  log(sigmoid(x)) is evaluated as
+// min(x,0) - log1p(exp(-|x|)) (finite where Keras' K.log(K.sigmoid(x)) underflows to -inf); derivatives in closed form
+// (d|x|/dx = sign(x), 0 at 0, as TF's AbsGrad).
+template <typename T>
+__device__ __forceinline__ T head_value(T x, int kind) {
+    const T a = x < T(0) ? -x : x;
+    switch (kind) {
+        case VCG_HEAD_SIGMOID: return T(1) / (T(1) + exp(-x));
+        case VCG_HEAD_LOGSIGM: return (x < T(0) ? x : T(0)) - log1p(exp(-a));
+        case VCG_HEAD_TANH: return tanh(x);
+        case VCG_HEAD_BILOG: return (x / (T(1) + a)) * log(a + T(2));
+        default: return x;
+    }
+}
+template <typename T>
+__device__ __forceinline__ T head_deriv(T x, int kind) {
+    const T a = x < T(0) ? -x : x;
+    switch (kind) {
+        case VCG_HEAD_SIGMOID: return T(1) / ((T(1) + exp(-x)) * (T(1) + exp(x)));   // s(x) s(-x): no 1 - s cancellation
+        case VCG_HEAD_LOGSIGM: return T(1) / (T(1) + exp(x));                  // 1 - sigmoid(x)
+        case VCG_HEAD_TANH: { const T u = exp(T(-2) * a); return T(4) * u / ((T(1) + u) * (T(1) + u)); }   // sech^2, no 1 - t^2 cancellation
+        case VCG_HEAD_BILOG: return log(a + T(2)) / ((T(1) + a) * (T(1) + a)) + a / ((T(1) + a) * (a + T(2)));
+        default: return T(1);
+    }
+}
+
+__global__ void head_act_fwd_kernel(const float* z, float* y, size_t count, int kind) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < count) y[i] = head_value<float>(z[i], kind);
+}
+
+__global__ void head_act_bwd_kernel(const float* z, const float* dy, float* dz, size_t count, int kind) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < count) dz[i] = dy[i] * head_deriv<float>(z[i], kind);
+}
+
+// loss = act((mean_a - mean_b) * mean_scale), evaluated in double by every thread from the two device scalars (no host
+// read: the step stays hipGraph-capturable); da[i] = act'(.) * ga, db[i] = act'(.) * gb  -- the broadcast gradients
+// of the two means.  One launch serves the relativistic D / G losses and (kind = none) the Wasserstein ones.
+__global__ void gan_loss_kernel(const float* mean_a, const float* mean_b, float mean_scale, int kind, float* loss_out,
+                                float* da, size_t na, float ga, float* db, size_t nb, float gb) {
+    const double delta = ((double)mean_a[0] - (mean_b ? (double)mean_b[0] : 0.0)) * (double)mean_scale;
+    const double g = head_deriv<double>(delta, kind);
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i == 0 && loss_out) loss_out[0] = (float)head_value<double>(delta, kind);
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t k = i; k < na; k += stride) da[k] = (float)(g * (double)ga);
+    for (size_t k = i; k < nb; k += stride) db[k] = (float)(g * (double)gb);
+}
+
 inline unsigned blocks_for(size_t count) { return (unsigned)((count + 255) / 256); }
 
 }  // namespace
@@ -300,9 +355,10 @@ int vcg_act_bwd(const float* saved, const float* dy, int n, int c, int hw, int a
                 const float* prelu_alpha, float* dx, float* dprelu_alpha, float* dsum, void* ws, size_t ws_bytes,
                 vcg_stream_t stream) {
     VCG_CHECK_PTR(saved); VCG_CHECK_PTR(dy); VCG_CHECK_PTR(dx);
-    if (n <= 0 || c <= 0 || hw <= 0 || (long)n * c > 65535) return VCG_E_SHAPE;
+    if (n <= 0 || c <= 0 || hw <= 0 || (long)n * c > 0x7fffffffL) return VCG_E_SHAPE;
     if (act == VCG_ACT_PRELU && prelu_alpha == nullptr) return VCG_E_NULL;
     hipStream_t st = (hipStream_t)stream;
+    const unsigned gy = (unsigned)((long)n * c > 65535 ? 65535 : n * c);
     int gx = ceil_div(hw, 256 * 4);
     if (gx > 64) gx = 64;
     if (gx < 1) gx = 1;
@@ -314,10 +370,10 @@ int vcg_act_bwd(const float* saved, const float* dy, int n, int c, int hw, int a
         if (dsum) part_sum = (float*)ws + (size_t)n * c * 64;
     }
     if (hw % 4 == 0) {
-        hipLaunchKernelGGL(act_bwd_kernel<true>, dim3(gx, (unsigned)(n * c)), dim3(256), 0, st, saved, dy, n, c, hw, act,
+        hipLaunchKernelGGL(act_bwd_kernel<true>, dim3(gx, gy), dim3(256), 0, st, saved, dy, n, c, hw, act,
                            act_alpha, prelu_alpha, dx, part_alpha, part_sum);
     } else {
-        hipLaunchKernelGGL(act_bwd_kernel<false>, dim3(gx, (unsigned)(n * c)), dim3(256), 0, st, saved, dy, n, c, hw, act,
+        hipLaunchKernelGGL(act_bwd_kernel<false>, dim3(gx, gy), dim3(256), 0, st, saved, dy, n, c, hw, act,
                            act_alpha, prelu_alpha, dx, part_alpha, part_sum);
     }
     VCG_LAUNCH_CHECK();
@@ -384,6 +440,38 @@ int vcg_pixel_loss(const float* pred, const float* target, size_t count, int kin
     return VCG_OK;
 }
 
+int vcg_head_act_fwd(const float* z, float* y, size_t count, int kind, vcg_stream_t stream) {
+    VCG_CHECK_PTR(z); VCG_CHECK_PTR(y);
+    if (kind < VCG_HEAD_NONE || kind > VCG_HEAD_BILOG) return VCG_E_UNSUPPORTED;
+    if (count == 0) return VCG_OK;
+    hipLaunchKernelGGL(head_act_fwd_kernel, dim3(blocks_for(count)), dim3(256), 0, (hipStream_t)stream, z, y, count, kind);
+    VCG_LAUNCH_CHECK();
+    return VCG_OK;
+}
+
+int vcg_head_act_bwd(const float* z, const float* dy, float* dz, size_t count, int kind, vcg_stream_t stream) {
+    VCG_CHECK_PTR(z); VCG_CHECK_PTR(dy); VCG_CHECK_PTR(dz);
+    if (kind < VCG_HEAD_NONE || kind > VCG_HEAD_BILOG) return VCG_E_UNSUPPORTED;
+    if (count == 0) return VCG_OK;
+    hipLaunchKernelGGL(head_act_bwd_kernel, dim3(blocks_for(count)), dim3(256), 0, (hipStream_t)stream, z, dy, dz, count, kind);
+    VCG_LAUNCH_CHECK();
+    return VCG_OK;
+}
+
+int vcg_gan_loss(const float* mean_a, const float* mean_b, float mean_scale, int kind, float* loss_out, float* da, size_t na,
+                 float ga, float* db, size_t nb, float gb, vcg_stream_t stream) {
+    VCG_CHECK_PTR(mean_a);
+    if (kind < VCG_HEAD_NONE || kind > VCG_HEAD_BILOG) return VCG_E_UNSUPPORTED;
+    if ((na && da == nullptr) || (nb && db == nullptr)) return VCG_E_NULL;
+    const size_t most = na > nb ? na : nb;
+    unsigned nbk = blocks_for(most ? most : 1);
+    if (nbk > 1024) nbk = 1024;
+    hipLaunchKernelGGL(gan_loss_kernel, dim3(nbk), dim3(256), 0, (hipStream_t)stream, mean_a, mean_b, mean_scale, kind, loss_out,
+                       da, na, ga, db, nb, gb);
+    VCG_LAUNCH_CHECK();
+    return VCG_OK;
+}
+
 int vcg_fill(float* y, size_t count, float value, vcg_stream_t stream) {
     VCG_CHECK_PTR(y);
     if (count == 0) return VCG_OK;
@@ -401,24 +489,24 @@ int vcg_axpby(const float* x, float* y, size_t count, float a, float b, vcg_stre
 }
 
 int vcg_adam_keras_multi(float* p, const float* g, float* m, float* v, size_t count, float lr_t, float beta_1,
-                         float beta_2, float eps, vcg_stream_t stream) {
+                         float beta_2, float eps, float grad_scale, vcg_stream_t stream) {
     VCG_CHECK_PTR(p); VCG_CHECK_PTR(g); VCG_CHECK_PTR(m); VCG_CHECK_PTR(v);
     if (count == 0) return VCG_OK;
     hipLaunchKernelGGL(adam_kernel, dim3(blocks_for(count)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, count, lr_t,
-                       beta_1, beta_2, eps);
+                       beta_1, beta_2, eps, grad_scale);
     VCG_LAUNCH_CHECK();
     return VCG_OK;
 }
 
 int vcg_adam_keras_multi_dev(float* p, const float* g, float* m, float* v, size_t count, float lr, float beta_1,
-                             float beta_2, float eps, int* t_dev, vcg_stream_t stream) {
+                             float beta_2, float eps, float grad_scale, int* t_dev, vcg_stream_t stream) {
     VCG_CHECK_PTR(p); VCG_CHECK_PTR(g); VCG_CHECK_PTR(m); VCG_CHECK_PTR(v); VCG_CHECK_PTR(t_dev);
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(adam_lr_kernel, dim3(1), dim3(64), 0, st, (int*)t_dev, lr, beta_1, beta_2);
     VCG_LAUNCH_CHECK();
     if (count) {
         hipLaunchKernelGGL(adam_dev_kernel, dim3(blocks_for(count)), dim3(256), 0, st, p, g, m, v, count, beta_1, beta_2, eps,
-                           (const int*)t_dev);
+                           grad_scale, (const int*)t_dev);
         VCG_LAUNCH_CHECK();
     }
     return VCG_OK;

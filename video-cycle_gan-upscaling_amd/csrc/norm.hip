@@ -46,15 +46,53 @@ __device__ __forceinline__ void for_each_in_slice(const GroupMap& gm, int g, siz
     }
 }
 
+// float4 variant: requires hw % 4 == 0 and slice bounds that are multiples of 4 (the host rounds `per` up to 4);
+// f(offset of 4 consecutive elements)
+template <typename F>
+__device__ __forceinline__ void for_each_in_slice4(const GroupMap& gm, int g, size_t beg, size_t end, F f) {
+    if (beg >= end) return;
+    if (gm.mode == VCG_NORM_INSTANCE) {
+        const size_t base = (size_t)g * gm.hw;
+        for (size_t i = beg + 4 * threadIdx.x; i < end; i += 1024) f(base + i);
+        return;
+    }
+    const size_t hw = (size_t)gm.hw;
+    const size_t n0 = beg / hw, n1 = (end - 1) / hw;
+    for (size_t nn = n0; nn <= n1; ++nn) {
+        const size_t lo = (beg > nn * hw ? beg : nn * hw) - nn * hw;
+        const size_t hi = (end < (nn + 1) * hw ? end : (nn + 1) * hw) - nn * hw;
+        const size_t base = (nn * gm.c + g) * hw;
+        for (size_t r = lo + 4 * threadIdx.x; r < hi; r += 1024) f(base + r);
+    }
+}
+
+// slice length: ceil(M / split), rounded up to a multiple of 4 when the float4 path is taken
+__device__ __forceinline__ size_t slice_len(size_t M, int split, bool vec) {
+    size_t per = (M + split - 1) / split;
+    if (vec) per = (per + 3) & ~(size_t)3;
+    return per;
+}
+
 // ---- statistics: shifted sums (shift = first element of the group) to avoid cancellation ---------
+template <bool VEC>
 __global__ __launch_bounds__(256) void stats_partial_kernel(const float* x, GroupMap gm, size_t M, int split,
                                                             float* part /* [G][split][2] */) {
     __shared__ float red[8];
     const int g = blockIdx.x / split, s = blockIdx.x % split;
     const float shift = x[gm.offset(g, 0)];
-    const size_t per = (M + split - 1) / split;
+    const size_t per = slice_len(M, split, VEC);
     const size_t beg = (size_t)s * per, end = beg + per < M ? beg + per : M;
     float v[2] = {0.f, 0.f};
+    if (VEC) {
+        float a0 = 0.f, a1 = 0.f, q0 = 0.f, q1 = 0.f;      // two chains per sum
+        for_each_in_slice4(gm, g, beg, end, [&](size_t o) {
+            const float4 t = *reinterpret_cast<const float4*>(x + o);
+            const float d0 = t.x - shift, d1 = t.y - shift, d2 = t.z - shift, d3 = t.w - shift;
+            a0 += d0 + d1; a1 += d2 + d3;
+            q0 += d0 * d0 + d1 * d1; q1 += d2 * d2 + d3 * d3;
+        });
+        v[0] = a0 + a1; v[1] = q0 + q1;
+    } else
     for_each_in_slice(gm, g, beg, end, [&](size_t o) {
         const float d = x[o] - shift;
         v[0] += d;
@@ -163,6 +201,7 @@ __device__ __forceinline__ float act_grad(float z, int act, float al) {
 }
 
 // pass 1: per group slice: sum dz, sum dz*xhat, sum dy*min(z,0)
+template <bool VEC>
 __global__ __launch_bounds__(256) void norm_bwd_partial_kernel(const float* x, const float* dy, GroupMap gm, size_t M,
                                                                int split, const float* mean, const float* invstd,
                                                                const float* gamma, const float* beta, int act,
@@ -174,18 +213,25 @@ __global__ __launch_bounds__(256) void norm_bwd_partial_kernel(const float* x, c
     const float mu = mean[g], is = invstd[g];
     const float ga = gamma ? gamma[ch] : 1.f, be = beta ? beta[ch] : 0.f;
     const float al = (act == VCG_ACT_PRELU) ? prelu[ch] : act_alpha;
-    const size_t per = (M + split - 1) / split;
+    const size_t per = slice_len(M, split, VEC);
     const size_t beg = (size_t)s * per, end = beg + per < M ? beg + per : M;
     float v[3] = {0.f, 0.f, 0.f};
-    for_each_in_slice(gm, g, beg, end, [&](size_t o) {
-        const float xh = (x[o] - mu) * is;
+    auto one = [&](float xv, float d) {
+        const float xh = (xv - mu) * is;
         const float z = ga * xh + be;
-        const float d = dy[o];
         const float dz = d * act_grad(z, act, al);
         v[0] += dz;
         v[1] += dz * xh;
         v[2] += d * fminf(z, 0.f);
-    });
+    };
+    if (VEC)
+        for_each_in_slice4(gm, g, beg, end, [&](size_t o) {
+            const float4 a = *reinterpret_cast<const float4*>(x + o);
+            const float4 d = *reinterpret_cast<const float4*>(dy + o);
+            one(a.x, d.x); one(a.y, d.y); one(a.z, d.z); one(a.w, d.w);
+        });
+    else
+        for_each_in_slice(gm, g, beg, end, [&](size_t o) { one(x[o], dy[o]); });
     block_sum<3>(v, red);
     if (threadIdx.x == 0) {
         float* o = part + ((size_t)g * split + s) * 3;
@@ -224,25 +270,40 @@ __global__ void norm_bwd_params_kernel(const float* sums, int n, int c, int mode
 }
 
 // pass 2: dx = gamma*invstd*(dz - sum_dz/M - xhat*sum_dz_xhat/M)
+template <bool VEC>
 __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const float* x, const float* dy, int n, int c, int hw,
                                                              int mode, const float* mean, const float* invstd,
                                                              const float* gamma, const float* beta, int act,
                                                              float act_alpha, const float* prelu, const float* sums,
                                                              float invM, int use_batch_stats, float* dx) {
-    const int plane = blockIdx.y;
-    const int ch = plane % c;
-    const int g = (mode == VCG_NORM_INSTANCE) ? plane : ch;
-    const float mu = mean[g], is = invstd[g];
-    const float ga = gamma ? gamma[ch] : 1.f, be = beta ? beta[ch] : 0.f;
-    const float al = (act == VCG_ACT_PRELU) ? prelu[ch] : act_alpha;
-    const float s0 = use_batch_stats ? sums[g * 3 + 0] * invM : 0.f;
-    const float s1 = use_batch_stats ? sums[g * 3 + 1] * invM : 0.f;
-    const size_t base = (size_t)plane * hw;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < hw; i += gridDim.x * 256) {
-        const float xh = (x[base + i] - mu) * is;
-        const float z = ga * xh + be;
-        const float dz = dy[base + i] * act_grad(z, act, al);
-        dx[base + i] = ga * is * (dz - s0 - xh * s1);
+    // gridDim.y is capped at 65535: the block walks the remaining planes (Dense BN: c = 1024, n >= 64)
+    for (int plane = blockIdx.y; plane < n * c; plane += gridDim.y) {
+        const int ch = plane % c;
+        const int g = (mode == VCG_NORM_INSTANCE) ? plane : ch;
+        const float mu = mean[g], is = invstd[g];
+        const float ga = gamma ? gamma[ch] : 1.f, be = beta ? beta[ch] : 0.f;
+        const float al = (act == VCG_ACT_PRELU) ? prelu[ch] : act_alpha;
+        const float s0 = use_batch_stats ? sums[g * 3 + 0] * invM : 0.f;
+        const float s1 = use_batch_stats ? sums[g * 3 + 1] * invM : 0.f;
+        const size_t base = (size_t)plane * hw;
+        const float gi = ga * is;
+        auto one = [&](float xv, float d) {
+            const float xh = (xv - mu) * is;
+            const float z = ga * xh + be;
+            const float dz = d * act_grad(z, act, al);
+            return gi * (dz - s0 - xh * s1);
+        };
+        if (VEC) {
+            for (int i = (blockIdx.x * 256 + threadIdx.x) * 4; i < hw; i += gridDim.x * 1024) {
+                const float4 a = *reinterpret_cast<const float4*>(x + base + i);
+                const float4 d = *reinterpret_cast<const float4*>(dy + base + i);
+                float4 o;
+                o.x = one(a.x, d.x); o.y = one(a.y, d.y); o.z = one(a.z, d.z); o.w = one(a.w, d.w);
+                *reinterpret_cast<float4*>(dx + base + i) = o;
+            }
+        } else {
+            for (int i = blockIdx.x * 256 + threadIdx.x; i < hw; i += gridDim.x * 256) dx[base + i] = one(x[base + i], dy[base + i]);
+        }
     }
 }
 
@@ -265,7 +326,10 @@ int vcg_norm_stats(const float* x, int n, int c, int hw, int mode, float* mean, 
     const size_t M = (mode == VCG_NORM_INSTANCE) ? (size_t)hw : (size_t)n * hw;
     const int split = pick_split(groups, M);
     GroupMap gm{n, c, hw, mode};
-    hipLaunchKernelGGL(stats_partial_kernel, dim3(groups * split), dim3(256), 0, st, x, gm, M, split, (float*)ws);
+    if (hw % 4 == 0)
+        hipLaunchKernelGGL(stats_partial_kernel<true>, dim3(groups * split), dim3(256), 0, st, x, gm, M, split, (float*)ws);
+    else
+        hipLaunchKernelGGL(stats_partial_kernel<false>, dim3(groups * split), dim3(256), 0, st, x, gm, M, split, (float*)ws);
     VCG_LAUNCH_CHECK();
     hipLaunchKernelGGL(stats_final_kernel, dim3(ceil_div(groups, 256)), dim3(256), 0, st, x, gm, M, split, groups,
                        (const float*)ws, mean, var);
@@ -336,8 +400,13 @@ int vcg_norm_act_bwd(const float* x, const float* dy, int n, int c, int hw, int 
     GroupMap gm{n, c, hw, mode};
     float* part = (float*)ws;
     float* sums = part + (size_t)groups * kMaxSplit * 3;
-    hipLaunchKernelGGL(norm_bwd_partial_kernel, dim3(groups * split), dim3(256), 0, st, x, dy, gm, M, split, mean,
-                       invstd, gamma, beta, act, act_alpha, prelu_alpha, part);
+    const bool vec = (hw % 4) == 0;
+    if (vec)
+        hipLaunchKernelGGL(norm_bwd_partial_kernel<true>, dim3(groups * split), dim3(256), 0, st, x, dy, gm, M, split, mean,
+                           invstd, gamma, beta, act, act_alpha, prelu_alpha, part);
+    else
+        hipLaunchKernelGGL(norm_bwd_partial_kernel<false>, dim3(groups * split), dim3(256), 0, st, x, dy, gm, M, split, mean,
+                           invstd, gamma, beta, act, act_alpha, prelu_alpha, part);
     VCG_LAUNCH_CHECK();
     hipLaunchKernelGGL(norm_bwd_final_kernel, dim3(ceil_div(groups, 256)), dim3(256), 0, st, (const float*)part, groups,
                        split, sums);
@@ -347,11 +416,15 @@ int vcg_norm_act_bwd(const float* x, const float* dy, int n, int c, int hw, int 
                            mode, dgamma, dbeta, dprelu_alpha);
         VCG_LAUNCH_CHECK();
     }
-    int gx = ceil_div(hw, 256);
+    int gx = ceil_div(hw, vec ? 1024 : 256);
     if (gx > 64) gx = 64;
-    hipLaunchKernelGGL(norm_bwd_apply_kernel, dim3(gx, (unsigned)(n * c)), dim3(256), 0, st, x, dy, n, c, hw, mode, mean,
-                       invstd, gamma, beta, act, act_alpha, prelu_alpha, (const float*)sums, 1.f / (float)M,
-                       use_batch_stats, dx);
+    const dim3 agrid(gx, (unsigned)((long)n * c > 65535 ? 65535 : n * c));
+    if (vec)
+        hipLaunchKernelGGL(norm_bwd_apply_kernel<true>, agrid, dim3(256), 0, st, x, dy, n, c, hw, mode, mean, invstd, gamma, beta, act,
+                           act_alpha, prelu_alpha, (const float*)sums, 1.f / (float)M, use_batch_stats, dx);
+    else
+        hipLaunchKernelGGL(norm_bwd_apply_kernel<false>, agrid, dim3(256), 0, st, x, dy, n, c, hw, mode, mean, invstd, gamma, beta, act,
+                           act_alpha, prelu_alpha, (const float*)sums, 1.f / (float)M, use_batch_stats, dx);
     VCG_LAUNCH_CHECK();
     return VCG_OK;
 }

@@ -32,6 +32,28 @@ __device__ __forceinline__ float apply_act(float v, int act, float alpha) {
 // (pointer and index are selected with scalar ops) instead of branching around every load.
 __device__ __attribute__((aligned(16))) const float vcg_zero_word[4] = {0.f, 0.f, 0.f, 0.f};
 
+// ---- buffer loads with hardware range checking (cdna_hip_programming.md T8) --------------------------------------
+// Staging loads of the convolution kernels read through a buffer descriptor: an element outside the tensor (zero
+// padding, channels past the end, ragged tile edges) is given the byte offset VCG_OOB and the hardware returns 0 for
+// it.  What matters is WHERE the mask sits: a select on the ADDRESS in front of the load, not on the DATA behind it --
+// a post-load `ok ? v : 0` makes the compiler wait for the whole prefetch (vmcnt(0)) before the MFMA loop it was
+// meant to fly under.  A descriptor covers < 4 GiB: callers base it on the image (n) they are working on.
+typedef __amdgpu_buffer_rsrc_t vcg_rsrc;
+constexpr unsigned VCG_OOB = 0xFFFFFFF0u;
+__device__ __forceinline__ vcg_rsrc make_rsrc(const void* base, size_t bytes) {
+    // the descriptor must be PROVABLY wave-uniform or hipcc wraps every load in a waterfall loop (guide T20): pass its
+    // inputs through readfirstlane as 32-bit halves and keep the saturation in 32-bit scalar arithmetic
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)base);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)((uintptr_t)base >> 32));
+    const unsigned blo = __builtin_amdgcn_readfirstlane((unsigned)bytes);
+    const unsigned bhi = __builtin_amdgcn_readfirstlane((unsigned)((unsigned long long)bytes >> 32));
+    const unsigned nrec = bhi ? 0xFFFFFFE0u : (blo > 0xFFFFFFE0u ? 0xFFFFFFE0u : blo);
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(((uintptr_t)hi << 32) | lo), 0, nrec, 0x00020000);
+}
+__device__ __forceinline__ float buf_load(vcg_rsrc r, unsigned byte_off) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)byte_off, 0, 0));
+}
+
 // wave64 sum via DPP-free shuffles
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

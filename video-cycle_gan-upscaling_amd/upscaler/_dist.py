@@ -24,8 +24,29 @@ def init_from_env(backend=None):
     return dist.group.WORLD
 
 
+def allreduce_sum(flat, group):
+    """in-place SUM over the ranks of one flat fp32 buffer (a model's whole gradient bucket, or the packed loss
+    scalars).  The 1/ranks of the mean is folded into the consumer kernel (vcg_adam_keras_multi's grad_scale,
+    vcg_gan_loss's mean_scale), so a data-parallel step adds one collective per bucket and no arithmetic pass."""
+    if group is None or flat.numel() == 0:
+        return flat
+    if flat.is_cuda and dist.get_backend(group) == "gloo":
+        # test rig only (several gloo ranks sharing one GPU, tests/test_dp_gpu.py): stage through the host
+        host = flat.detach().cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+        flat.copy_(host)
+        return flat
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    return flat
+
+
+def world_size(group):
+    return 1 if group is None else dist.get_world_size(group)
+
+
 def allreduce_mean(flat, group):
-    """in-place mean over the ranks of one flat fp32 buffer (the model's whole gradient bucket)."""
+    """host-side helper (CPU tensors: tests, launch scripts): in-place mean over the ranks.  The device path of the
+    trainer uses allreduce_sum and folds the division into its kernels."""
     if group is None or flat.numel() == 0:
         return flat
     if flat.is_cuda and dist.get_backend(group) == "gloo":

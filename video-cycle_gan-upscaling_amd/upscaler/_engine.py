@@ -37,6 +37,7 @@ class Runtime:
         self.lib = L.load()
         self.device = L.require_gpu()
         self._ws = None
+        self._ws_retired = []   # outgrown workspaces stay allocated: recorded hipGraphs keep writing through their pointers
         self.prof = None      # optional kernel-timing hook set by bench.py
 
     @classmethod
@@ -50,9 +51,16 @@ class Runtime:
         return torch.cuda.current_stream().cuda_stream
 
     def workspace(self, nbytes):
+        """scratch for partial sums (wgrad / norm / loss reductions), shared by all layers on the stream.  It only grows,
+        and an outgrown buffer is never freed: a captured train step or inference graph has its address baked into its
+        kernel nodes and would otherwise write into memory the allocator may have handed to a live tensor.  Doubling
+        keeps the retired buffers below the size of the current one in total."""
         nbytes = max(int(nbytes), 4096)
         if self._ws is None or self._ws.numel() < nbytes:
-            self._ws = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8, device=self.device)
+            if self._ws is not None:
+                self._ws_retired.append(self._ws)
+                nbytes = max(nbytes, 2 * self._ws.numel())
+            self._ws = torch.empty(nbytes + 4096, dtype=torch.uint8, device=self.device)
         return self._ws.data_ptr(), self._ws.numel()
 
     def empty(self, *shape):
@@ -829,12 +837,33 @@ def maxpool2x2_bwd(rt, x, dy):
     return dx
 
 
-def mean_scalar(rt, t):
-    """device scalar tensor holding mean(t) (vcg_mean_reduce)."""
-    out = rt.empty(1)
+def mean_scalar(rt, t, out=None):
+    """device scalar tensor holding mean(t) (vcg_mean_reduce); ``out``: a 1-element fp32 view to write it to."""
+    if out is None:
+        out = rt.empty(1)
     ws, wsn = rt.workspace(rt.lib.vcg_mean_reduce_workspace_bytes(t.numel()))
     L.check(rt.lib.vcg_mean_reduce(t.data_ptr(), t.numel(), out.data_ptr(), ws, wsn, rt.stream), "vcg_mean_reduce")
     return out
+
+
+def head_act_fwd(rt, z, kind):
+    """discriminator output activation (model.py:885-892); kind: _lib.HEAD_*"""
+    y = rt.empty(*z.shape)
+    L.check(rt.lib.vcg_head_act_fwd(z.data_ptr(), y.data_ptr(), z.numel(), kind, rt.stream), "vcg_head_act_fwd")
+    return y
+
+
+def head_act_bwd(rt, z, dy, kind):
+    dz = rt.empty(*z.shape)
+    L.check(rt.lib.vcg_head_act_bwd(z.data_ptr(), dy.data_ptr(), dz.data_ptr(), z.numel(), kind, rt.stream), "vcg_head_act_bwd")
+    return dz
+
+
+def gan_loss(rt, mean_a, mean_b, mean_scale, kind, loss_out, da, ga, db=None, gb=0.0):
+    """loss_out = act((mean_a - mean_b) * mean_scale); da[:] = act' * ga, db[:] = act' * gb -- all on the device"""
+    L.check(rt.lib.vcg_gan_loss(mean_a.data_ptr(), _ptr(mean_b), float(mean_scale), kind, _ptr(loss_out), _ptr(da),
+                                da.numel() if da is not None else 0, float(ga), _ptr(db), db.numel() if db is not None else 0,
+                                float(gb), rt.stream), "vcg_gan_loss")
 
 
 def filled_like(rt, t, value):

@@ -17,7 +17,7 @@ BatchNormalization layers in inference mode.  Here that pass is
 accumulation and the epilogue arithmetic fp32; the weights are rounded to bf16 once, when the engine is built or
 ``refresh()`` is called after a weight update.  The folded BatchNormalization parameters
 (scale = gamma / sqrt(moving_var + 1e-3), shift = (bias - moving_mean) * scale + beta) are 64-element fp32 vectors
-computed with torch ops at build time -- parameter preparation, not part of the per-frame path."""
+derived by vcg_axpby + vcg_norm_finalize when the engine is built or refreshed."""
 import ctypes
 
 import numpy as np
@@ -54,12 +54,19 @@ class Bf16Generator:
         return out
 
     def _fold(self, conv, norm):
-        ps = conv.ps
+        """scale = gamma / sqrt(moving_var + eps), shift = (bias - moving_mean) * scale + beta, by the same kernels the
+        training path uses: vcg_axpby forms (moving_mean - bias), vcg_norm_finalize turns it into scale / shift"""
+        rt, ps = self.rt, conv.ps
+        c = conv.cout
         if self.instance:          # non-affine instance norm: only the convolution's bias is applied in its epilogue
-            return torch.ones(conv.cout, device=self.rt.device), ps[conv.name + "/bias"]
-        scale = ps[norm.name + "/gamma"] / torch.sqrt(ps[norm.name + "/moving_variance"] + BN_EPS)
-        shift = (ps[conv.name + "/bias"] - ps[norm.name + "/moving_mean"]) * scale + ps[norm.name + "/beta"]
-        return scale.contiguous(), shift.contiguous()
+            return E.filled_like(rt, ps[conv.name + "/bias"], 1.0), ps[conv.name + "/bias"]
+        mean = ps[norm.name + "/moving_mean"].clone()
+        E.axpby(rt, ps[conv.name + "/bias"], mean, -1.0, 1.0)
+        scale, shift = rt.empty(c), rt.empty(c)
+        L.check(rt.lib.vcg_norm_finalize(mean.data_ptr(), ps[norm.name + "/moving_variance"].data_ptr(), ps[norm.name + "/gamma"].data_ptr(),
+                                         ps[norm.name + "/beta"].data_ptr(), c, 1, BN_EPS, scale.data_ptr(), shift.data_ptr(), None, None, None,
+                                         0.0, 0, rt.stream), "vcg_norm_finalize")
+        return scale, shift
 
     def refresh(self):
         """(re)derive the packed bf16 weights and the folded BatchNormalization vectors from the model's parameters"""

@@ -14,6 +14,8 @@ LIB_PATH = os.path.join(_PKG_DIR, "libvcg_hip.so")
 ACT_NONE, ACT_LRELU, ACT_PRELU, ACT_TANH = 0, 1, 2, 3
 NORM_BATCH, NORM_INSTANCE = 0, 1
 LOSS_MSE, LOSS_MAE = 0, 1
+HEAD_NONE, HEAD_SIGMOID, HEAD_LOGSIGM, HEAD_TANH, HEAD_BILOG = 0, 1, 2, 3, 4
+HEAD_KINDS = {None: 0, "none": 0, "sigmoid": 1, "log-sigm": 2, "tanh": 3, "bi-log": 4}
 
 
 class ConvDesc(ctypes.Structure):
@@ -71,8 +73,11 @@ SIGNATURES = {
     "vcg_pixel_loss": (c_int, [_P, _P, c_size_t, c_int, c_float, _P, _P, _P, c_size_t, _P]),
     "vcg_fill": (c_int, [_P, c_size_t, c_float, _P]),
     "vcg_axpby": (c_int, [_P, _P, c_size_t, c_float, c_float, _P]),
-    "vcg_adam_keras_multi": (c_int, [_P, _P, _P, _P, c_size_t, c_float, c_float, c_float, c_float, _P]),
-    "vcg_adam_keras_multi_dev": (c_int, [_P, _P, _P, _P, c_size_t, c_float, c_float, c_float, c_float, _P, _P]),
+    "vcg_adam_keras_multi": (c_int, [_P, _P, _P, _P, c_size_t, c_float, c_float, c_float, c_float, c_float, _P]),
+    "vcg_adam_keras_multi_dev": (c_int, [_P, _P, _P, _P, c_size_t, c_float, c_float, c_float, c_float, c_float, _P, _P]),
+    "vcg_head_act_fwd": (c_int, [_P, _P, c_size_t, c_int, _P]),
+    "vcg_head_act_bwd": (c_int, [_P, _P, _P, c_size_t, c_int, _P]),
+    "vcg_gan_loss": (c_int, [_P, _P, c_float, c_int, _P, _P, c_size_t, c_float, _P, c_size_t, c_float, _P]),
     "vcg_frames_u8_to_nchw": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
     "vcg_nchw_to_frames_u8": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
     "vcg_nhwc_to_nchw": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),

@@ -515,6 +515,7 @@ class DiscriminatorStack(Model):
     def __init__(self, input_shape, filters, activation, seed, name):
         super().__init__(name, input_shape, seed)
         self.activation = activation
+        self.head = L.HEAD_KINDS.get(activation, L.HEAD_NONE)     # any other string: no activation, like the reference's if/elif chain
         self.convs = []
         cin = input_shape[2]
         h, w = input_shape[0], input_shape[1]
@@ -556,14 +557,16 @@ class DiscriminatorStack(Model):
             h, a = dn.forward(h); tape.append(a)
             h, a = bn.forward(h, training, update_moving=update_moving); tape.append(a)
         h, a = self.d3.forward(h); tape.append(a)
-        if self.activation not in (None, "none"):
-            raise NotImplementedError("discriminator output activation %r: train with activation='none' "
-                                      "(the reference's default, model.py:836)" % (self.activation,))
+        if self.head:                                  # model.py:885-892: optional squashing of the critic's output
+            tape.append(h)
+            h = E.head_act_fwd(self.rt, h, self.head)
         return h, tape
 
     def backward(self, tape, dy, need_dx=False, param_grads=True, which=0):
         rt = self.rt
         tape = list(tape)
+        if self.head:
+            dy = E.head_act_bwd(rt, tape.pop(), dy, self.head)
         d = self.d3.backward(tape.pop(), dy, True, param_grads, which)
         for dn, bn in ((self.d2, self.b2), (self.d1, self.b1)):
             d = bn.backward(tape.pop(), d, param_grads, which)
@@ -587,6 +590,7 @@ class DiscriminatorPatchGAN(Model):
     def __init__(self, input_shape, activation, norm, seed):
         super().__init__("discriminator_patchgan_70", input_shape, seed)
         self.activation = activation
+        self.head = L.HEAD_KINDS.get(activation, L.HEAD_NONE)
         self.convs = []
         cin = input_shape[2]
         for i, (f, s, has_norm) in enumerate(self.SPEC):
@@ -615,13 +619,16 @@ class DiscriminatorPatchGAN(Model):
             h, a = cv.forward(h, tag="d_conv"); tape.append(a)
             if na is not None:
                 h, a = na.forward(h, training, update_moving=update_moving); tape.append(a)
-        if self.activation not in (None, "none"):
-            raise NotImplementedError("discriminator output activation %r" % (self.activation,))
+        if self.head:
+            tape.append(h)
+            h = E.head_act_fwd(self.rt, h, self.head)
         return h, tape
 
     def backward(self, tape, dy, need_dx=False, param_grads=True, which=0):
         tape = list(tape)
         d = dy
+        if self.head:
+            d = E.head_act_bwd(self.rt, tape.pop(), d, self.head)
         for i, (cv, na) in reversed(list(enumerate(self.convs))):
             if na is not None:
                 d = na.backward(tape.pop(), d, param_grads, which)
@@ -660,26 +667,26 @@ def make_discriminator_patchgan_70(input_shape, activation="none", norm="instanc
 # =================================================================================================
 # training wiring -- make_and_compile_gan / make_and_compile_gan2 / compile_training_model
 # =================================================================================================
-def _pixel_loss(rt, pred, target, kind, scale):
+def _pixel_loss(rt, pred, target, kind, scale, out=None):
     """(value [1], d(scale * value)/d pred) of the mean squared / absolute difference of two device tensors"""
-    val, dpred = rt.empty(1), rt.empty(*pred.shape)
+    val, dpred = (rt.empty(1) if out is None else out), rt.empty(*pred.shape)
     ws, wsn = rt.workspace(rt.lib.vcg_mean_reduce_workspace_bytes(pred.numel()))
     L.check(rt.lib.vcg_pixel_loss(pred.data_ptr(), target.data_ptr(), pred.numel(), L.LOSS_MSE if kind == "mse" else L.LOSS_MAE,
                                   float(scale), val.data_ptr(), dpred.data_ptr(), ws, wsn, rt.stream), "vcg_pixel_loss")
     return val, dpred
 
 
-def _content_loss_and_grad(rt, kind, weight, fake, hr):
+def _content_loss_and_grad(rt, kind, weight, fake, hr, out=None):
     """content loss value (device scalar, unweighted) and d(weight * loss)/d fake for 'mse' / 'mae' or a VGG19
     perceptual loss object (model.py:101-157): features of hr and fake at block5_conv4, their mean squared / absolute
     difference, its gradient back through the frozen VGG19 to the fake frames, plus ``rate`` x the pixel term."""
     if isinstance(kind, str):
-        return _pixel_loss(rt, fake, hr, kind, weight)
+        return _pixel_loss(rt, fake, hr, kind, weight, out)
     vgg = kind.model
     f_real, _ = vgg.forward(hr)
     f_fake, tape = vgg.forward(fake)
     pk = "mae" if kind.kind == "vgg_mae" else "mse"
-    val, dfeat = _pixel_loss(rt, f_fake, f_real, pk, weight)
+    val, dfeat = _pixel_loss(rt, f_fake, f_real, pk, weight, out)
     dfake = vgg.backward_data(tape, dfeat)
     if kind.rate:
         pval, dpix = _pixel_loss(rt, fake, hr, pk, weight * kind.rate)
@@ -698,7 +705,15 @@ class _Slots:
 
 
 class GanTrainer:
-    """Shared state behind the three training models: who updates what, with which loss."""
+    """Shared state behind the three training models: who updates what, with which loss.
+
+    The loop body (train_gan3.py:346-354) is held as a *plan*: kernel-only segments separated by the collectives of data
+    parallelism.  Run eagerly it is the three reference calls; recorded, every run of consecutive segments is one hipGraph
+    (one graph per step on a single GPU).  No segment reads a device value on the host: the GAN losses -- including the
+    relativistic ones' non-linearity and its derivative (model.py:244-259) -- are evaluated by vcg_gan_loss from the two
+    mean(D(.)) scalars where they lie.  The four reported losses are left in one packed device buffer
+        lossbuf = [d_a, d_b, content, adversarial]     (loss_disc = wa*d_a - wb*d_b)
+    and read (one D2H copy; under DP one 4-float all-reduce) when the caller asks for the Keras return values."""
 
     def __init__(self, generator, discriminator, wiring, content_kind, content_w, losses, disc_w, optimizer,
                  process_group=None):
@@ -710,122 +725,167 @@ class GanTrainer:
         self.opt = optimizer
         self.g_slots, self.d_slots = _Slots(generator), _Slots(discriminator)
         self.pg = process_group
+        from . import _dist
+        self.world = _dist.world_size(process_group)
         self._t_dev = None          # device copy of optimizer.iterations (graph-replayable Adam)
         self._graph = None
+        self._lossbuf = self.rt.zeros(4)
+        self._means = self.rt.zeros(2)
+        self._loss_w = (1.0, 0.0)
+        self.relativistic = bool(losses is not None and losses.relativistic)
+        self.loss_kind = L.HEAD_KINDS[losses.loss_activation_name] if self.relativistic else L.HEAD_NONE
 
-    # -- pieces ---------------------------------------------------------------------------------------
-    def _sync_grads(self, model, which=0):
-        """DP: mean of the model's flat gradient bucket over the ranks (one RCCL all-reduce)."""
+    # -- collectives (data parallelism; never inside a recorded segment) -------------------------------
+    def _reduce_grads(self, model, which=0):
+        """DP: SUM of the model's flat gradient bucket over the ranks (one RCCL all-reduce); Adam applies the 1/ranks."""
         if self.pg is not None:
             from . import _dist
-            _dist.allreduce_mean(model.ps.grads if which == 0 else model.ps.grads2, self.pg)
+            _dist.allreduce_sum(model.ps.grads if which == 0 else model.ps.grads2, self.pg)
 
+    _sync_grads = _reduce_grads
+
+    def _reduce_means(self):
+        """DP, relativistic losses: the two mean(D(.)) scalars pass through a non-linearity before back-prop, so they
+        must be the GLOBAL batch's: one 2-float all-reduce, its 1/ranks folded into vcg_gan_loss."""
+        if self.pg is not None:
+            from . import _dist
+            _dist.allreduce_sum(self._means, self.pg)
+
+    @property
+    def _mean_scale(self):
+        return 1.0 / self.world if (self.relativistic and self.pg is not None) else 1.0
+
+    # -- optimizer ------------------------------------------------------------------------------------
     def _adam(self, model, slots, which=0):
-        self._sync_grads(model, which)
+        self._reduce_grads(model, which)
         self._apply_adam(model, slots, which)
 
     def _apply_adam(self, model, slots, which=0):
         rt = self.rt
         ps = model.ps
         g = ps.grads if which == 0 else ps.grads2
+        gs = 1.0 / self.world
         if self._t_dev is not None:
             L.check(rt.lib.vcg_adam_keras_multi_dev(ps.params.data_ptr(), g.data_ptr(), slots.m.data_ptr(), slots.v.data_ptr(),
                                                     ps.n_trainable, float(self.opt.lr), float(self.opt.beta_1),
-                                                    float(self.opt.beta_2), float(self.opt.epsilon), self._t_dev.data_ptr(),
+                                                    float(self.opt.beta_2), float(self.opt.epsilon), gs, self._t_dev.data_ptr(),
                                                     rt.stream), "vcg_adam_keras_multi_dev")
         else:
             L.check(rt.lib.vcg_adam_keras_multi(ps.params.data_ptr(), g.data_ptr(), slots.m.data_ptr(), slots.v.data_ptr(),
                                                 ps.n_trainable, float(self.opt.lr_t()), float(self.opt.beta_1),
-                                                float(self.opt.beta_2), float(self.opt.epsilon), rt.stream),
+                                                float(self.opt.beta_2), float(self.opt.epsilon), gs, rt.stream),
                     "vcg_adam_keras_multi")
         self.opt.iterations += 1
         model.refresh()
 
-    def _global_mean(self, t):
-        """mean over the GLOBAL batch, available on the device right away (relativistic losses feed it through a
-        non-linearity before back-prop: SURVEY.md section 8e)."""
-        m = E.mean_scalar(self.rt, t)
-        if self.pg is not None:
-            from . import _dist
-            _dist.allreduce_mean(m, self.pg)
-        return m
-
-    def _mean(self, t):
-        """mean that only feeds a reported loss value: kept rank-local here, averaged over the ranks when the
-        value is read (``_host_scalars``), so that the step itself holds no scalar collective."""
-        if self.losses is not None and self.losses.relativistic:
-            return self._global_mean(t)
-        return E.mean_scalar(self.rt, t)
-
-    def _host_scalars(self, tensors):
-        """read device scalars (rank-local means over equal shards) as python floats of the global batch"""
-        v = torch.stack([x.reshape(()) for x in tensors])
-        if self.pg is not None:          # (already-global values are unchanged by the mean)
-            from . import _dist
-            _dist.allreduce_mean(v, self.pg)
-        return [float(x) for x in v.tolist()]
-
-    # -- the three reference calls ----------------------------------------------------------------------
+    # -- segments of the loop body ---------------------------------------------------------------------
     def predict(self, lr_nchw):
         y, _ = self.G.forward(lr_nchw, training=False)
         return y
 
+    def _disc_forward(self, s, hr, fake):
+        """D on the real and on the generated batch; their output means (model.py:220-224,244-248 / train_gan.py:305-315)"""
+        rt, D = self.rt, self.D
+        if self.wiring == "gan2":
+            s["out_r"], s["tape_r"] = D.forward(hr, True, True)
+            s["out_f"], s["tape_f"] = D.forward(fake, True, True)
+            E.mean_scalar(rt, s["out_r"], out=self._means[0:1])
+            E.mean_scalar(rt, s["out_f"], out=self._means[1:2])
+            self._loss_w = (1.0, 0.0)
+        else:
+            x = torch.cat([hr, fake], 0)       # device-side concatenation of the two batches (memory op)
+            out, s["tape"] = D.forward(x, True, True)
+            nb = hr.shape[0]
+            per = out.numel() // out.shape[0]
+            tot = out.numel()
+            s["out"], s["nreal"] = out, nb * per
+            E.mean_scalar(rt, out[:nb], out=self._lossbuf[0:1])
+            E.mean_scalar(rt, out[nb:], out=self._lossbuf[1:2])
+            self._loss_w = (nb * per / tot, (tot - nb * per) / tot)
+
+    def _disc_backward(self, s):
+        """loss (device scalar) and its broadcast gradients, D backward on both applications into two gradient buffers"""
+        rt, D = self.rt, self.D
+        if self.wiring == "gan2":
+            out_r, out_f = s.pop("out_r"), s.pop("out_f")
+            dyr, dyf = rt.empty(*out_r.shape), rt.empty(*out_f.shape)
+            E.gan_loss(rt, self._means[0:1], self._means[1:2], self._mean_scale, self.loss_kind, self._lossbuf[0:1],
+                       dyr, 1.0 / out_r.numel(), dyf, -1.0 / out_f.numel())
+            D.backward(s.pop("tape_r"), dyr, False, True, 0)
+            D.backward(s.pop("tape_f"), dyf, False, True, 1)
+            E.axpby(rt, D.ps.grads2, D.ps.grads, 1.0, 1.0)
+        else:
+            out, nreal = s.pop("out"), s.pop("nreal")
+            tot = out.numel()
+            dy = rt.empty(*out.shape)
+            L.check(rt.lib.vcg_fill(dy.data_ptr(), nreal, 1.0 / tot, rt.stream), "vcg_fill")
+            L.check(rt.lib.vcg_fill(dy.data_ptr() + 4 * nreal, tot - nreal, -1.0 / tot, rt.stream), "vcg_fill")
+            D.backward(s.pop("tape"), dy, False, True, 0)
+
+    def _gan_forward(self, s, lr, hr):
+        """G forward with batch statistics, frozen D on the fakes (and on the real batch for the relativistic loss),
+        content loss value + gradient (model.py:1103-1123)"""
+        rt, G, D = self.rt, self.G, self.D
+        fake, s["gtape"] = G.forward(lr, True)
+        s["out_f"], s["dtape"] = D.forward(fake, True, False)          # frozen D: batch stats, no moving update
+        _, s["dfake"] = _content_loss_and_grad(rt, self.content_kind, self.cw, fake, hr, out=self._lossbuf[2:3])
+        E.mean_scalar(rt, s["out_f"], out=self._means[0:1])
+        if self.relativistic:
+            out_r, _ = D.forward(hr, True, False)
+            E.mean_scalar(rt, out_r, out=self._means[1:2])
+
+    def _gan_backward(self, s):
+        rt, G, D = self.rt, self.G, self.D
+        out_f = s.pop("out_f")
+        dyf = rt.empty(*out_f.shape)
+        E.gan_loss(rt, self._means[0:1], self._means[1:2] if self.relativistic else None, self._mean_scale, self.loss_kind,
+                   self._lossbuf[3:4], dyf, self.dw / out_f.numel())
+        d_adv = D.backward(s.pop("dtape"), dyf, True, False, 0)
+        dfake = s.pop("dfake")
+        E.axpby(rt, d_adv, dfake, 1.0, 1.0)
+        G.backward(s.pop("gtape"), dfake, 0)
+
+    def _plan(self, lr, hr):
+        """the loop body as [(is_collective, callable)]"""
+        s = {}
+        dp = self.pg is not None
+        rel_dp = dp and self.relativistic
+        P = [(False, lambda: self._disc_forward(s, hr, self.predict(lr)))]
+        if rel_dp:
+            P.append((True, self._reduce_means))
+        P.append((False, lambda: self._disc_backward(s)))
+        if dp:
+            P.append((True, lambda: self._reduce_grads(self.D)))
+        P.append((False, lambda: (self._apply_adam(self.D, self.d_slots), self._gan_forward(s, lr, hr))))
+        if rel_dp:
+            P.append((True, self._reduce_means))
+        P.append((False, lambda: self._gan_backward(s)))
+        if dp:
+            P.append((True, lambda: self._reduce_grads(self.G)))
+        P.append((False, lambda: self._apply_adam(self.G, self.g_slots)))
+        return P
+
+    # -- the reference's calls --------------------------------------------------------------------------
     def disc_step(self, hr, fake, apply=True):
         """disc_train.train_on_batch (train_gan3.py:353 / train_gan.py:315).  hr, fake: device NCHW.
         apply=False stops after the local gradients (the caller syncs and applies them)."""
-        rt, D = self.rt, self.D
-        if self.wiring == "gan2":
-            out_r, tape_r = D.forward(hr, True, True)
-            out_f, tape_f = D.forward(fake, True, True)
-            mr, mf = self._mean(out_r), self._mean(out_f)
-            if self.losses.relativistic:
-                delta = float(mr.item()) - float(mf.item())
-                val, g = _act_value_and_grad(self.losses.loss_activation_name, delta)
-                loss = val
-            else:
-                g, loss = 1.0, None
-            D.backward(tape_r, E.filled_like(rt, out_r, g / out_r.numel()), False, True, 0)
-            D.backward(tape_f, E.filled_like(rt, out_f, -g / out_f.numel()), False, True, 1)
-            E.axpby(rt, D.ps.grads2, D.ps.grads, 1.0, 1.0)
-            if loss is None:
-                loss = (mr, mf)
-        else:
-            x = torch.cat([hr, fake], 0)       # device-side concatenation of the two batches (memory op)
-            out, tape = D.forward(x, True, True)
-            nb = hr.shape[0]
-            per = out.numel() // out.shape[0]
-            dy = rt.empty(*out.shape)
-            tot = out.numel()
-            L.check(rt.lib.vcg_fill(dy.data_ptr(), nb * per, 1.0 / tot, rt.stream), "vcg_fill")
-            L.check(rt.lib.vcg_fill(dy.data_ptr() + 4 * nb * per, tot - nb * per, -1.0 / tot, rt.stream), "vcg_fill")
-            D.backward(tape, dy, False, True, 0)
-            mr = E.mean_scalar(rt, out[:nb])
-            mf = E.mean_scalar(rt, out[nb:])
-            loss = (mr, mf, nb * per / tot, (tot - nb * per) / tot)
+        s = {}
+        self._disc_forward(s, hr, fake)
+        if self.relativistic:
+            self._reduce_means()
+        self._disc_backward(s)
         if apply:
-            self._adam(D, self.d_slots)
-        return loss
+            self._adam(self.D, self.d_slots)
 
     def gan_step(self, lr, hr, apply=True):
         """gan_train.train_on_batch (train_gan3.py:354 / train_gan.py:317)."""
-        rt, G, D = self.rt, self.G, self.D
-        fake, gtape = G.forward(lr, True)
-        out_f, dtape = D.forward(fake, True, False)          # frozen D: batch stats, no moving update
-        content, dfake = _content_loss_and_grad(rt, self.content_kind, self.cw, fake, hr)
-        mf = self._mean(out_f)
-        adv = mf
-        g = 1.0
-        if self.wiring == "gan2" and self.losses.relativistic:
-            out_r, _ = D.forward(hr, True, False)
-            mr = self._global_mean(out_r)
-            delta = float(mf.item()) - float(mr.item())
-            adv, g = _act_value_and_grad(self.losses.loss_activation_name, delta)
-        d_adv = D.backward(dtape, E.filled_like(rt, out_f, self.dw * g / out_f.numel()), True, False, 0)
-        E.axpby(rt, d_adv, dfake, 1.0, 1.0)
-        G.backward(gtape, dfake, 0)
+        s = {}
+        self._gan_forward(s, lr, hr)
+        if self.relativistic:
+            self._reduce_means()
+        self._gan_backward(s)
         if apply:
-            self._adam(G, self.g_slots)
-        return content, adv
+            self._adam(self.G, self.g_slots)
 
     # -- checkpoint / resume (the reference only ever saves the generator: train_gan3.py:364-368) -----------
     def save_state(self, path):
@@ -855,46 +915,47 @@ class GanTrainer:
             self._t_dev[0] = self.opt.iterations
 
     # -- loss read-back ---------------------------------------------------------------------------------
-    def disc_loss_value(self, loss):
-        if isinstance(loss, tuple):
-            mr, mf = self._host_scalars(loss[:2])
-            if len(loss) == 2:
-                return mr - mf
-            return mr * loss[2] - mf * loss[3]
-        return float(loss)
+    def read_losses(self):
+        """(loss_disc, loss_gan, loss_gan_gen, loss_gan_disc) of the last step as python floats: ONE device->host copy
+        of the packed buffer; under DP one 4-float all-reduce in front of it (rank-local means over equal shards average
+        to the global batch's; already-global relativistic values are unchanged by the average)."""
+        v = self._lossbuf
+        if self.pg is not None:
+            from . import _dist
+            v = _dist.allreduce_sum(v.clone(), self.pg)
+        a, b, c, adv = (x / self.world for x in v.tolist())
+        wa, wb = self._loss_w
+        return wa * a - wb * b, self.cw * c + self.dw * adv, c, adv
 
-    def gan_loss_values(self, content, adv):
-        if isinstance(adv, torch.Tensor):
-            c, a = self._host_scalars([content, adv])
-        else:
-            c, a = self._host_scalars([content])[0], float(adv)
-        return [self.cw * c + self.dw * a, c, a]
+    def disc_loss_value(self):
+        return self.read_losses()[0]
 
-    def train_step(self, lr, hr):
+    def gan_loss_values(self):
+        return list(self.read_losses()[1:])
+
+    def train_step(self, lr, hr, read_losses=True):
         """One loop-body iteration (train_gan3.py:346-354) without host round trips between the three
         calls; lr/hr are device NCHW tensors.  Returns (loss_disc, loss_gan, loss_gan_gen, loss_gan_disc)."""
-        fake = self.predict(lr)
-        ld = self.disc_step(hr, fake)
-        content, adv = self.gan_step(lr, hr)
-        ld = self.disc_loss_value(ld)
-        lg = self.gan_loss_values(content, adv)
-        return ld, lg[0], lg[1], lg[2]
+        for _, fn in self._plan(lr, hr):
+            fn()
+        return self.read_losses() if read_losses else None
 
-    # -- hipGraph: the whole loop body as ONE graph launch (three around the two all-reduces under DP) ------
+    # -- hipGraph: the whole loop body as ONE graph launch (more under DP, cut at its collectives) ----------
     def capture_train_step(self, lr, hr):
-        """Capture predict -> disc_step -> gan_step for these (static-shape) device batches into a hipGraph.
-        Later ``train_step_graph(lr, hr)`` copies the new frames into the captured input buffers and replays:
-        ~700 kernel launches become one graph launch (no per-kernel host cost, no launch gaps).  Available when
-        no host read sits inside the step (Wasserstein / v1 losses).
+        """Record the loop body for these (static-shape) device batches.  Later ``train_step_graph(lr, hr)`` copies the
+        new frames into the captured input buffers and replays: ~700 kernel launches become one graph launch (no
+        per-kernel host cost, no launch gaps) -- for every loss the reference offers, the relativistic ones included.
 
-        Under data parallelism the step is cut at its two exchange points into three graphs
+        Under data parallelism the plan is cut at its collectives into several graphs (Wasserstein: three --
             A: predict, D forward x2, D backward x2        -> all-reduce(D gradient bucket)
             B: Adam(D), G forward, D forward, D/G backward -> all-reduce(G gradient bucket)
             C: Adam(G)
-        and the two RCCL all-reduces are issued eagerly between the replays (collectives stay outside the
-        graphs: nothing about RCCL capture is assumed)."""
-        if self.losses is not None and self.losses.relativistic:
-            raise NotImplementedError("graph capture needs a step without host reads inside")
+        relativistic: five, with the two 2-float mean all-reduces in addition) and the RCCL calls are issued eagerly
+        between the replays: nothing about RCCL graph capture is assumed.
+
+        Every lazily cached derived weight (per-tap transposed kernels, packed bf16 copies) is invalidated before the
+        recording, so its derivation is part of the graph at each point of use: weights changed from outside between two
+        replays (load_state, set_weights_dict, a broadcast) are picked up by the next replay."""
         rt = self.rt
         if self._t_dev is None:
             self._t_dev = torch.tensor([self.opt.iterations, 0], dtype=torch.int32, device=rt.device)    # {t, lr_t scratch}
@@ -902,32 +963,38 @@ class GanTrainer:
         self.train_step(self._g_lr, self._g_hr)        # eager warm-up with the device-side counter (lazy buffers exist)
         torch.cuda.synchronize()
         it0 = self.opt.iterations
+        for m in (self.G, self.D) + ((self.content_kind.model,) if isinstance(self.content_kind, _VggLossBase) else ()):
+            m.refresh()
+        plan = self._plan(self._g_lr, self._g_hr)
+        items, run = [], []
+        for is_coll, fn in plan + [(True, None)]:
+            if not is_coll:
+                run.append(fn)
+                continue
+            if run:
+                items.append(("graph", list(run)))
+                run = []
+            if fn is not None:
+                items.append(("coll", fn))
+        graphs, pool, seq = [], None, []
         # capture_error_mode="thread_local": the RCCL watchdog thread may poll its events while this thread records
-        if self.pg is None:
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
-                fake = self.predict(self._g_lr)
-                ld = self.disc_step(self._g_hr, fake)
-                content, adv = self.gan_step(self._g_lr, self._g_hr)
-            graphs = [graph]
-        else:
-            ga, gb, gc = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-            with torch.cuda.graph(ga, capture_error_mode="thread_local"):
-                fake = self.predict(self._g_lr)
-                ld = self.disc_step(self._g_hr, fake, apply=False)
-            pool = ga.pool()
-            with torch.cuda.graph(gb, pool=pool, capture_error_mode="thread_local"):
-                self._apply_adam(self.D, self.d_slots)
-                content, adv = self.gan_step(self._g_lr, self._g_hr, apply=False)
-            with torch.cuda.graph(gc, pool=pool, capture_error_mode="thread_local"):
-                self._apply_adam(self.G, self.g_slots)
-            graphs = [ga, gb, gc]
+        for kind, what in items:
+            if kind == "coll":
+                seq.append(what)
+                continue
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=pool, capture_error_mode="thread_local"):
+                for fn in what:
+                    fn()
+            pool = g.pool()
+            graphs.append(g)
+            seq.append(g)
         # capture only records: undo the host-side counter advance of the recording pass
         self.opt.iterations = it0
-        self._graph, self._g_out = graphs, (ld, content, adv)
+        self._graph, self._seq = graphs, seq
         return graphs[0] if len(graphs) == 1 else graphs
 
-    def train_step_graph(self, lr=None, hr=None):
+    def train_step_graph(self, lr=None, hr=None, read_losses=True):
         """Replay the captured loop body (optionally on new frames of the captured shape)."""
         if self._graph is None:
             raise RuntimeError("call capture_train_step first")
@@ -935,20 +1002,13 @@ class GanTrainer:
             self._g_lr.copy_(lr)
         if hr is not None:
             self._g_hr.copy_(hr)
-        if len(self._graph) == 1:
-            self._graph[0].replay()
-        else:
-            ga, gb, gc = self._graph
-            ga.replay()
-            self._sync_grads(self.D)
-            gb.replay()
-            self._sync_grads(self.G)
-            gc.replay()
+        for item in self._seq:
+            if isinstance(item, torch.cuda.CUDAGraph):
+                item.replay()
+            else:
+                item()
         self.opt.iterations += 2
-        ld, content, adv = self._g_out
-        ldv = self.disc_loss_value(ld)
-        lg = self.gan_loss_values(content, adv)
-        return ldv, lg[0], lg[1], lg[2]
+        return self.read_losses() if read_losses else None
 
 
 class TrainingModel:
@@ -975,22 +1035,26 @@ class TrainingModel:
         if self.kind == "disc":
             if t.wiring == "gan2":
                 hr, fake = x
-                loss = t.disc_step(E.to_device_nchw(rt, hr), E.to_device_nchw(rt, fake))
+                t.disc_step(E.to_device_nchw(rt, hr), E.to_device_nchw(rt, fake))
             else:
                 xs = E.to_device_nchw(rt, x)
                 yv = np.asarray(y).reshape(-1)
                 nb = int((yv > 0).sum())
                 if not (np.all(yv[:nb] == 1) and np.all(yv[nb:] == -1)):
                     raise NotImplementedError("v1 discriminator targets must be (+1...,-1...) as in train_gan.py:309-313")
-                loss = t.disc_step(xs[:nb], xs[nb:])
-            return t.disc_loss_value(loss)
+                t.disc_step(xs[:nb], xs[nb:])
+            return t.disc_loss_value()
         if self.kind == "gan":
             if t.wiring == "gan2":
                 lr, hr = x
             else:
                 lr, hr = x, (y[0] if isinstance(y, (list, tuple)) else y)
-            content, adv = t.gan_step(E.to_device_nchw(rt, lr), E.to_device_nchw(rt, hr))
-            return t.gan_loss_values(content, adv)
+                # wasserstein_loss = mean(y_true * y_pred) (model.py:159-160): sign and scale of the adversarial term come from
+                # the caller's targets; the reference passes +1 (train_gan.py:310,317) and that is what the device step computes
+                if isinstance(y, (list, tuple)) and len(y) > 1 and not np.all(np.asarray(y[1]) == 1):
+                    raise NotImplementedError("v1 gan_train targets for the discriminator output must be +1 (train_gan.py:310-317)")
+            t.gan_step(E.to_device_nchw(rt, lr), E.to_device_nchw(rt, hr))
+            return t.gan_loss_values()
         raise NotImplementedError("gen_train.train_on_batch is never called by the reference's GAN loop; "
                                   "use compile_training_model for generator-only training")
 
@@ -1068,7 +1132,7 @@ class GeneratorTrainingModel:
         ps = G.ps
         L.check(rt.lib.vcg_adam_keras_multi(ps.params.data_ptr(), ps.grads.data_ptr(), self.slots.m.data_ptr(),
                                             self.slots.v.data_ptr(), ps.n_trainable, float(self.opt.lr_t()),
-                                            float(self.opt.beta_1), float(self.opt.beta_2), float(self.opt.epsilon), rt.stream),
+                                            float(self.opt.beta_1), float(self.opt.beta_2), float(self.opt.epsilon), 1.0, rt.stream),
                 "vcg_adam_keras_multi")
         self.opt.iterations += 1
         G.refresh()
