@@ -201,26 +201,35 @@ __global__ __launch_bounds__(256, (KH >= 9 ? 1 : 2)) void conv_fwd_kernel(const 
         store_chunk();
         __syncthreads();
         if (c + 1 < nchunks) load_chunk((c + 1) * CK);   // in flight during this chunk's MFMAs
+        // operand fragments are read one tap AHEAD of the MFMAs that use them (register double buffer, statically renamed
+        // by the full unroll); sched_group_barrier pins the order "reads of tap t+1, then the 4*XT MFMAs of tap t", so a
+        // wave's own LDS latency hides under its own MFMAs instead of relying on the SIMD's other wave
+        constexpr int NTAP = (CK / 2) * C::T;
+        auto rd = [&](int q, float (&a)[2], float (&b)[2][XT]) {
+            const int cp = q / C::T, t = q % C::T, ky = t / KW, kx = t % KW;
+            a[0] = abase[(cp * 2 * C::T + t) * 64];
+            a[1] = abase[(cp * 2 * C::T + t) * 64 + 32];
 #pragma unroll
-        for (int cp = 0; cp < CK / 2; ++cp) {
-#pragma unroll
-            for (int ky = 0; ky < KH; ++ky) {
-#pragma unroll
-                for (int kx = 0; kx < KW; ++kx) {
-                    const int t = ky * KW + kx;
-                    const float a0 = abase[(cp * 2 * C::T + t) * 64];
-                    const float a1 = abase[(cp * 2 * C::T + t) * 64 + 32];
-#pragma unroll
-                    for (int xt = 0; xt < XT; ++xt) {
-                        const float b0 = bbase[cp * 2 * C::PLANE + ky * C::IW + kx + xt * 32 * S];
-                        const float b1 = bbase[cp * 2 * C::PLANE + (S + ky) * C::IW + kx + xt * 32 * S];
-                        acc[0][0][xt] = mfma32(a0, b0, acc[0][0][xt]);
-                        acc[0][1][xt] = mfma32(a0, b1, acc[0][1][xt]);
-                        acc[1][0][xt] = mfma32(a1, b0, acc[1][0][xt]);
-                        acc[1][1][xt] = mfma32(a1, b1, acc[1][1][xt]);
-                    }
-                }
+            for (int xt = 0; xt < XT; ++xt) {
+                b[0][xt] = bbase[cp * 2 * C::PLANE + ky * C::IW + kx + xt * 32 * S];
+                b[1][xt] = bbase[cp * 2 * C::PLANE + (S + ky) * C::IW + kx + xt * 32 * S];
             }
+        };
+        float a_[2][2], b_[2][2][XT];
+        rd(0, a_[0], b_[0]);
+#pragma unroll
+        for (int q = 0; q < NTAP; ++q) {
+            const int cur = q & 1, nxt = cur ^ 1;
+            if (q + 1 < NTAP) rd(q + 1, a_[nxt], b_[nxt]);
+#pragma unroll
+            for (int xt = 0; xt < XT; ++xt) {
+                acc[0][0][xt] = mfma32(a_[cur][0], b_[cur][0][xt], acc[0][0][xt]);
+                acc[0][1][xt] = mfma32(a_[cur][0], b_[cur][1][xt], acc[0][1][xt]);
+                acc[1][0][xt] = mfma32(a_[cur][1], b_[cur][0][xt], acc[1][0][xt]);
+                acc[1][1][xt] = mfma32(a_[cur][1], b_[cur][1][xt], acc[1][1][xt]);
+            }
+            if (q + 1 < NTAP) __builtin_amdgcn_sched_group_barrier(0x100, 1 + 2 * XT, 0);   // DS reads of the next tap first
+            __builtin_amdgcn_sched_group_barrier(0x008, 4 * XT, 0);                          // then this tap's MFMAs
         }
     }
 
