@@ -285,6 +285,36 @@ size_t vcg_conv2d_bf16_wgrad_workspace_bytes(const vcg_conv_desc* d);
 int vcg_conv2d_bf16_wgrad(const vcg_conv_desc* d, const void* x, const void* dy, float* dw_hwio, float* dbias, void* ws, size_t ws_bytes,
                           hipStream_t stream);
 
+/* ---- generic bf16 NHWC Conv2D (any 3x3 / 4x4 / 5x5, stride 1-3, channels multiples of 32 / 16): the discriminators' layers in
+ * the bf16 configs (upscaling/upscaler/model.py:839-871, 904-936; PatchGAN) and the generator's Conv2DTranspose gradients.
+ * Weights as MFMA operand fragments: vcg_pack_conv_frag_bf16(w, taps, mdim, kdim, mode, out), out = taps*mdim*kdim bf16:
+ *   mode 0: w is a Keras (kh,kw,in,out) kernel, packed for the forward pass       (mdim = out, kdim = in)
+ *   mode 1: the same kernel packed for its data gradient                           (mdim = in,  kdim = out)
+ * (a Conv2DTranspose kernel (kh,kw,out,in) is a Conv2D kernel with the roles of in / out exchanged.) */
+size_t vcg_conv_frag_bf16_bytes(int taps, int mdim, int kdim);
+int vcg_pack_conv_frag_bf16(const float* w, int taps, int mdim, int kdim, int mode, void* out, hipStream_t stream);
+/* y = act(conv(x) + bias), x / y bf16 NHWC, bias fp32 [cout] or NULL, act VCG_ACT_NONE / VCG_ACT_LRELU */
+int vcg_conv2d_nhwc_bf16_fwd(const vcg_conv_desc* d, const void* x, const void* wfrag, const float* bias, int act, float act_alpha,
+                             void* y, hipStream_t stream);
+/* dx = data gradient of the layer d describes (d is the FORWARD layer), dy / dx bf16 NHWC, wfrag_t packed with mode 1.
+ * mask_src (optional, bf16 NHWC of dx's shape): dx *= (mask_src > 0 ? 1 : mask_slope), the derivative of a LeakyReLU whose
+ * OUTPUT mask_src is and which feeds the layer. */
+int vcg_conv2d_nhwc_bf16_dgrad(const vcg_conv_desc* d, const void* dy, const void* wfrag_t, const void* mask_src, float mask_slope,
+                               void* dx, hipStream_t stream);
+/* weight / bias gradient, x [n][h][w][cin] and dy [n][oh][ow][cout] bf16 NHWC, 3x3 / 4x4, stride 1 / 2, channels multiples of 64;
+ * dw fp32 in Keras' (kh,kw,in,out) layout, dbias fp32 [cout] or NULL (deterministic: fixed-order sum of per-workgroup partials) */
+size_t vcg_conv2d_nhwc_bf16_wgrad_workspace_bytes(const vcg_conv_desc* d);
+int vcg_conv2d_nhwc_bf16_wgrad(const vcg_conv_desc* d, const void* x, const void* dy, float* dw_hwio, float* dbias, void* ws, size_t ws_bytes,
+                               hipStream_t stream);
+/* Conv2DTranspose(strides=2,'same') (upscaling/upscaler/model.py:72): weight gradient from the layer input x [n][h][w][cin] and the
+ * gradient dz [n][oh][ow][cout] in front of its activation, both bf16 NHWC; dw fp32 in Keras' (kh,kw,out,in) layout */
+size_t vcg_conv_transpose2d_nhwc_bf16_wgrad_workspace_bytes(const vcg_conv_desc* d);
+int vcg_conv_transpose2d_nhwc_bf16_wgrad(const vcg_conv_desc* d, const void* x, const void* dz, float* dw_hwoi, void* ws, size_t ws_bytes,
+                                         hipStream_t stream);
+/* flat precision changes (Flatten of an NHWC tensor IS its memory order: the Dense head of the discriminators stays fp32) */
+int vcg_bf16_to_f32(const void* x, float* y, size_t count, hipStream_t stream);
+int vcg_f32_to_bf16(const float* x, void* y, size_t count, hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

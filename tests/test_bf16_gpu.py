@@ -563,3 +563,61 @@ def test_bf16_generator_modes_graph_replay_matches_eager(rt, mode):
     assert oe == og, (oe, og)
     assert torch.equal(ge, gg) and torch.equal(de, dg)
     assert all(np.isfinite(v) for step in og for v in step)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# generic bf16 NHWC convolution (the discriminators' layers in the bf16 configs): forward, data and weight gradient
+# ---------------------------------------------------------------------------------------------------------------
+GCONV_CASES = [
+    # cin, cout, k, stride, padding, n, h, w
+    (64, 128, 4, 2, 1, 2, 32, 32),             # PatchGAN block 2
+    (128, 256, 4, 2, 1, 1, 16, 16),            # PatchGAN block 3
+    (256, 512, 4, 1, 1, 1, 10, 10),            # PatchGAN block 4 (ragged: 9x9 output)
+    (64, 128, 3, 2, "same", 2, 32, 32),        # simple_512 / thin_512 block 2 (TF-SAME: pads (0,1))
+    (128, 128, 3, 2, "same", 1, 15, 17),       # odd sizes: pads (1,1), ragged tiles
+    (512, 512, 3, 2, "same", 2, 4, 4),
+    (512, 512, 3, 2, "same", 3, 2, 2),         # 2x2 -> 1x1
+    (64, 64, 3, 1, "same", 1, 9, 20),
+    (64, 128, 4, 2, 1, 3, 70, 38),             # many tiles, several images
+]
+
+
+@pytest.mark.parametrize("cin,cout,k,stride,padding,n,h,w", GCONV_CASES)
+def test_generic_conv_bf16_fwd_dgrad_wgrad(rt, cin, cout, k, stride, padding, n, h, w):
+    """Conv2DBf16 (vcg_conv2d_nhwc_bf16_fwd / _dgrad / _wgrad) against the fp64 oracle on the same bf16-rounded operands:
+    outputs that are stored in bf16 to 2^-8 max-norm, the fp32 weight / bias gradients to 1e-4."""
+    from oracle import keras_ops as K
+    from upscaler import _engine as E
+    layer = E.Conv2DBf16("c", cin, cout, k, stride, padding)
+    ps = E.ParamStore()
+    layer.declare(ps)
+    ps.materialize(rt)
+    layer.bind(rt, ps)
+    g = torch.Generator().manual_seed(cin + cout + k * 7 + h)
+    wk = torch.randn(k, k, cin, cout, generator=g) * (2.0 / (k * k * cin)) ** 0.5
+    bk = torch.randn(cout, generator=g) * 0.1
+    ps.set_weights({"c/kernel": wk.numpy(), "c/bias": bk.numpy()})
+    x = torch.randn(n, cin, h, w, generator=g)
+    xr = _bf16_round(x).requires_grad_(True)
+    wr = _bf16_round(wk).requires_grad_(True)
+    br = bk.double().requires_grad_(True)
+    yr = K.conv2d(xr, wr, br, stride, padding)
+    dy = torch.randn(*yr.shape, generator=g)
+    dyr = _bf16_round(dy)
+    (yr * dyr).sum().backward()
+
+    xd = _to_nhwc_bf16(rt, x.to(rt.device))
+    y, ctx = layer.forward(xd)
+    assert tuple(y.shape) == (n, yr.shape[2], yr.shape[3], cout)
+    dx = layer.backward(ctx, _to_nhwc_bf16(rt, dy.to(rt.device)), True, True, 0)
+    e_y = rel_err(_to_nchw_f32(rt, y), yr)
+    e_dx = rel_err(_to_nchw_f32(rt, dx), xr.grad)
+    e_dw = rel_err(ps.grad("c/kernel"), wr.grad)
+    e_db = rel_err(ps.grad("c/bias"), br.grad)
+    report("generic bf16 conv %d->%d k%d s%d pad=%s n=%d %dx%d: fwd=%.2e dgrad=%.2e wgrad=%.2e dbias=%.2e" % (cin, cout, k, stride, padding, n, h, w, e_y, e_dx, e_dw, e_db))
+    assert e_y < TOL_BF16 and e_dx < TOL_BF16
+    assert e_dw < 1e-4 and e_db < 1e-4
+    # deterministic: a second backward reproduces the gradients bit for bit
+    g1 = ps.grad("c/kernel").clone()
+    layer.backward(ctx, _to_nhwc_bf16(rt, dy.to(rt.device)), False, True, 0)
+    assert torch.equal(g1, ps.grad("c/kernel"))

@@ -1,0 +1,327 @@
+// Generic bf16 NHWC convolution on v_mfma_f32_32x32x16_bf16 -- forward and data gradient of every Conv2D the
+// discriminators instantiate in the bf16 configs (BASELINE.json C3/C4): 3x3 / 4x4 / 5x5, stride 1 / 2, 64...512 channels
+// (upscaling/upscaler/model.py:839-871 simple_512, :904-936 thin_512; the PatchGAN extension), and the data gradient of
+// the generator's Conv2DTranspose (model.py:72).
+//
+// Implicit GEMM, A = weights (rows = output channels), B = activations (columns = 32 output pixels), k = (tap, 16 input
+// channels).  With NHWC a lane's B fragment -- 8 consecutive channels of ITS pixel -- is one 16-byte load, whatever the
+// stride, padding or tap: the kernel streams both operands straight into registers, no LDS image, no barrier, every wave on
+// its own.  Weights are re-laid out once per optimizer step as MFMA operand fragments ([tap][k-step][32-row block][lane] x
+// 16 bytes), so a wave's A fragment is one coalesced 1-KiB load that all waves of the chip share through L1 / L2; the
+// activation loads go through a range-checked buffer descriptor (padding and ragged tiles read as zero, vcg_common.hpp).
+// The discriminators' tensors are small (<= 67 MB at batch 8) and L2-resident: what bounds the kernel is the vector L1 /
+// address path (one 16-byte load per MFMA and wave), i.e. it cannot reach the MFMA roof the LDS-tiled trunk kernel aims
+// at -- but it serves every shape with one code path at several times the fp32 kernels' rate, and the data gradient of a
+// strided convolution is the same kernel run once per output phase with that phase's tap list.
+#include "vcg_common.hpp"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int GC_MAXTAPS = 25;
+
+struct GcTap { short dy, dx, wt, pad; };
+
+struct GcParams {
+    const void* x;          // bf16 NHWC [n][ih][iw][kch]
+    const void* wf;         // fragments [wt][kch/16][mblocks][64 lanes] x 16 bytes
+    void* y;                // bf16 NHWC [n][oh][ow][mch]
+    const float* bias;      // [mch] or null
+    const void* mask_src;   // optional bf16 NHWC tensor of the output's shape: out *= (mask_src > 0 ? 1 : mask_slope)
+    size_t wbytes;
+    int n, ih, iw, kch;     // input tensor
+    int oh, ow, mch;        // output tensor
+    int loh, low;           // logical output grid of this launch (a phase of a strided data gradient, or the whole output)
+    int osy, osx, ooy, oox; // output pixel = (ly*osy + ooy, lx*osx + oox)
+    int isy, isx;           // input pixel  = (ly*isy + tap.dy, lx*isx + tap.dx)
+    int ntaps, mblocks;
+    int act;
+    float alpha, mask_slope;
+    GcTap taps[GC_MAXTAPS];
+};
+
+__device__ __forceinline__ void swap32u(float& a, float& b) {
+    const u32x2 sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    a = __uint_as_float(sw.x);
+    b = __uint_as_float(sw.y);
+}
+
+__device__ __forceinline__ bf16x8 ld_frag(vcg_rsrc r, unsigned off) {
+    return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0));
+}
+
+// workgroup = 4 waves; wave = 64 output channels (2 MFMA row blocks) x NT tiles of 32 consecutive logical pixels
+template <int NT>
+__global__ __launch_bounds__(256, (NT == 4 ? 2 : 3)) void gconv_bf16_kernel(const GcParams p) {
+    const int lane = threadIdx.x & 63, r = lane & 31, hh = lane >> 5;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int mb0 = blockIdx.y * 2;                                     // first 32-row block of this workgroup
+    const bool two = mb0 + 1 < p.mblocks;                               // (mch = 32: only one row block)
+    const long total = (long)p.n * p.loh * p.low;
+    const long tile0 = ((long)blockIdx.x * 4 + wv) * NT;              // first pixel tile of this wave
+    if (tile0 * 32 >= total) return;
+
+    // this lane's pixel in each tile: coordinates in the logical grid
+    int img[NT], ly[NT], lx[NT];
+    bool pok[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const long P = (tile0 + t) * 32 + r;
+        pok[t] = P < total;
+        const long Pc = pok[t] ? P : 0;
+        lx[t] = (int)(Pc % p.low);
+        const long q = Pc / p.low;
+        ly[t] = (int)(q % p.loh);
+        img[t] = (int)(q / p.loh);
+    }
+    const vcg_rsrc rx = make_rsrc(p.x, (size_t)p.n * p.ih * p.iw * p.kch * 2);
+    const vcg_rsrc rw = make_rsrc(p.wf, p.wbytes);
+    const int ksteps = p.kch >> 4;
+    const unsigned wlane = (unsigned)lane * 16u;
+    const unsigned wstep = (unsigned)p.mblocks * 1024u;                 // bytes between k-steps of one tap
+
+    f32x16 acc[2][NT];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[m][t][e] = 0.f;
+
+    for (int ti = 0; ti < p.ntaps; ++ti) {
+        const GcTap tp = p.taps[ti];
+        unsigned xoff[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int iy = ly[t] * p.isy + tp.dy, ix = lx[t] * p.isx + tp.dx;
+            const bool ok = pok[t] && (unsigned)iy < (unsigned)p.ih && (unsigned)ix < (unsigned)p.iw;
+            xoff[t] = ok ? (unsigned)((((long)img[t] * p.ih + iy) * p.iw + ix) * p.kch + 8 * hh) * 2u : VCG_OOB;
+        }
+        unsigned woff = ((unsigned)tp.wt * ksteps * p.mblocks + mb0) * 1024u + wlane;
+        // two k-steps per iteration: all loads of both first, then their MFMAs (the other waves of the SIMD cover the latency)
+        int ks = 0;
+        for (; ks + 2 <= ksteps; ks += 2) {
+            bf16x8 a[2][2], b[2][NT];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                a[u][0] = ld_frag(rw, woff + u * wstep);
+                a[u][1] = ld_frag(rw, two ? woff + u * wstep + 1024u : VCG_OOB);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) b[u][t] = ld_frag(rx, xoff[t] == VCG_OOB ? VCG_OOB : xoff[t] + (unsigned)(ks + u) * 32u);
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[u][0], b[u][t], acc[0][t], 0, 0, 0);
+                    acc[1][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[u][1], b[u][t], acc[1][t], 0, 0, 0);
+                }
+            woff += 2 * wstep;
+        }
+        if (ks < ksteps) {                                               // odd number of k-steps (kch = 16, 48, ...)
+            const bf16x8 a0 = ld_frag(rw, woff), a1 = ld_frag(rw, two ? woff + 1024u : VCG_OOB);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const bf16x8 b = ld_frag(rx, xoff[t] == VCG_OOB ? VCG_OOB : xoff[t] + (unsigned)ks * 32u);
+                acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b, acc[0][t], 0, 0, 0);
+                acc[1][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b, acc[1][t], 0, 0, 0);
+            }
+        }
+    }
+
+    // epilogue: y = act(acc + bias) [* mask] -> bf16.  An MFMA tile leaves lane (pixel r, half hh) with channels
+    // 8g + 4hh + {0..3}; v_permlane32_swap between register groups (2q, 2q+1) of the two half-waves turns that into 8
+    // consecutive channels 16q + 8hh + {0..7}: one 16-byte store per (row block, q)
+    const float slope = p.act == VCG_ACT_LRELU ? p.alpha : 1.f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int oy = ly[t] * p.osy + p.ooy, ox = lx[t] * p.osx + p.oox;
+        const bool ok = pok[t] && oy < p.oh && ox < p.ow;
+        const long obase = (((long)img[t] * p.oh + oy) * p.ow + ox) * p.mch;
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int co = (mb0 + m) * 32 + 16 * q + 8 * hh;
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float lo = acc[m][t][8 * q + j], hi = acc[m][t][8 * q + 4 + j];
+                    swap32u(lo, hi);
+                    v[j] = lo;
+                    v[4 + j] = hi;
+                }
+                if (!ok || (m == 1 && !two)) continue;
+                bf16x8 mk;
+                if (p.mask_src) mk = *(const bf16x8*)((const __bf16*)p.mask_src + obase + co);
+                bf16x8 o;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    float u = v[j] + (p.bias ? p.bias[co + j] : 0.f);
+                    u = u >= 0.f ? u : u * slope;
+                    if (p.mask_src) u *= ((float)mk[j] > 0.f ? 1.f : p.mask_slope);
+                    o[j] = (__bf16)u;
+                }
+                *(bf16x8*)((__bf16*)p.y + obase + co) = o;
+            }
+    }
+}
+
+// out[((wt*ksteps + ks)*mblocks + mb)*64 + lane][j] = W(m = mb*32 + (lane&31), k = ks*16 + 8*(lane>>5) + j, tap wt)
+//   mode 0: W(m, k, t) = w[(t*kdim + k)*mdim + m]     a Keras (kh,kw,in,out) kernel read as conv forward  (m = out, k = in)
+//   mode 1: W(m, k, t) = w[(t*mdim + m)*kdim + k]     the same kernel read for its data gradient          (m = in,  k = out)
+__global__ void pack_frag_kernel(const float* __restrict__ w, __bf16* __restrict__ out, int taps, int mdim, int kdim, int mode) {
+    const int ksteps = kdim >> 4, mblocks = mdim >> 5;
+    const long total = (long)taps * ksteps * mblocks * 64 * 8;
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int j = (int)(idx & 7), lane = (int)((idx >> 3) & 63);
+        long q = idx >> 9;
+        const int mb = (int)(q % mblocks); q /= mblocks;
+        const int ks = (int)(q % ksteps);
+        const int t = (int)(q / ksteps);
+        const int m = mb * 32 + (lane & 31), k = ks * 16 + 8 * (lane >> 5) + j;
+        const float v = mode == 0 ? w[((long)t * kdim + k) * mdim + m] : w[((long)t * mdim + m) * kdim + k];
+        out[idx] = (__bf16)v;
+    }
+}
+
+__global__ void bf16_to_f32_kernel(const __bf16* __restrict__ x, float* __restrict__ y, size_t count) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < count) y[i] = (float)x[i];
+}
+
+__global__ void f32_to_bf16_kernel(const float* __restrict__ x, __bf16* __restrict__ y, size_t count) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < count) y[i] = (__bf16)x[i];
+}
+
+int launch_gconv(GcParams& p, hipStream_t st) {
+    const long total = (long)p.n * p.loh * p.low;
+    if (total <= 0) return VCG_OK;
+    const long tiles = (total + 31) / 32;
+    // 4 tiles per wave (128 accumulator registers, half the operand loads per MFMA) once there is enough work to fill the chip
+    const int mgroups = (p.mblocks + 1) / 2;
+    const bool big = tiles * mgroups >= 4096;
+    const int nt = big ? 4 : 2;
+    const long wgs = (tiles + 4 * nt - 1) / (4 * nt);
+    if (wgs > 0x7fffffffL) return VCG_E_SHAPE;
+    const dim3 grid((unsigned)wgs, (unsigned)mgroups);
+    if (big) hipLaunchKernelGGL(gconv_bf16_kernel<4>, grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(gconv_bf16_kernel<2>, grid, dim3(256), 0, st, p);
+    VCG_LAUNCH_CHECK();
+    return VCG_OK;
+}
+
+int check_gdesc(const vcg_conv_desc* d) {
+    if (d == nullptr) return VCG_E_NULL;
+    if (d->n <= 0 || d->cin <= 0 || d->h <= 0 || d->w <= 0 || d->cout <= 0 || d->oh <= 0 || d->ow <= 0) return VCG_E_SHAPE;
+    if (d->kh <= 0 || d->kw <= 0 || d->kh * d->kw > GC_MAXTAPS || d->stride < 1 || d->stride > 3) return VCG_E_UNSUPPORTED;
+    if (d->pad_top < 0 || d->pad_left < 0 || d->pad_top >= d->kh || d->pad_left >= d->kw) return VCG_E_SHAPE;
+    if (d->cin % 16 || d->cout % 16) return VCG_E_UNSUPPORTED;
+    if ((size_t)d->n * d->h * d->w * d->cin * 2 > 0xFFFFFFE0u || (size_t)d->n * d->oh * d->ow * d->cout * 2 > 0xFFFFFFE0u) return VCG_E_SHAPE;
+    return VCG_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t vcg_conv_frag_bf16_bytes(int taps, int mdim, int kdim) { return (size_t)taps * mdim * kdim * 2; }
+
+int vcg_pack_conv_frag_bf16(const float* w, int taps, int mdim, int kdim, int mode, void* out, hipStream_t stream) {
+    VCG_CHECK_PTR(w); VCG_CHECK_PTR(out);
+    if (taps <= 0 || mdim <= 0 || kdim <= 0 || mdim % 32 || kdim % 16 || (mode != 0 && mode != 1)) return VCG_E_UNSUPPORTED;
+    const long total = (long)taps * mdim * kdim;
+    hipLaunchKernelGGL(pack_frag_kernel, dim3((unsigned)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256)), dim3(256), 0, stream, w,
+                       (__bf16*)out, taps, mdim, kdim, mode);
+    VCG_LAUNCH_CHECK();
+    return VCG_OK;
+}
+
+int vcg_bf16_to_f32(const void* x, float* y, size_t count, hipStream_t stream) {
+    VCG_CHECK_PTR(x); VCG_CHECK_PTR(y);
+    if (count == 0) return VCG_OK;
+    hipLaunchKernelGGL(bf16_to_f32_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, stream, (const __bf16*)x, y, count);
+    VCG_LAUNCH_CHECK();
+    return VCG_OK;
+}
+
+int vcg_f32_to_bf16(const float* x, void* y, size_t count, hipStream_t stream) {
+    VCG_CHECK_PTR(x); VCG_CHECK_PTR(y);
+    if (count == 0) return VCG_OK;
+    hipLaunchKernelGGL(f32_to_bf16_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, stream, x, (__bf16*)y, count);
+    VCG_LAUNCH_CHECK();
+    return VCG_OK;
+}
+
+// y[n][oh][ow][cout] = act(conv(x) + bias): d describes the Keras layer (pads = TF-SAME "before" pads or explicit padding)
+int vcg_conv2d_nhwc_bf16_fwd(const vcg_conv_desc* d, const void* x, const void* wfrag, const float* bias, int act, float act_alpha,
+                             void* y, hipStream_t stream) {
+    int rc = check_gdesc(d);
+    if (rc) return rc;
+    VCG_CHECK_PTR(x); VCG_CHECK_PTR(wfrag); VCG_CHECK_PTR(y);
+    if (d->cout % 32) return VCG_E_UNSUPPORTED;
+    if (act != VCG_ACT_NONE && act != VCG_ACT_LRELU) return VCG_E_UNSUPPORTED;
+    GcParams p{};
+    p.x = x; p.wf = wfrag; p.y = y; p.bias = bias;
+    p.wbytes = vcg_conv_frag_bf16_bytes(d->kh * d->kw, d->cout, d->cin);
+    p.n = d->n; p.ih = d->h; p.iw = d->w; p.kch = d->cin;
+    p.oh = d->oh; p.ow = d->ow; p.mch = d->cout;
+    p.loh = d->oh; p.low = d->ow; p.osy = p.osx = 1; p.ooy = p.oox = 0;
+    p.isy = p.isx = d->stride;
+    p.mblocks = d->cout / 32;
+    p.act = act; p.alpha = act_alpha;
+    for (int ky = 0; ky < d->kh; ++ky)
+        for (int kx = 0; kx < d->kw; ++kx) p.taps[p.ntaps++] = GcTap{(short)(ky - d->pad_top), (short)(kx - d->pad_left), (short)(ky * d->kw + kx), 0};
+    return launch_gconv(p, stream);
+}
+
+// dx[n][h][w][cin] = data gradient of the layer d describes, from dy[n][oh][ow][cout]; wfrag_t: the kernel packed with mode 1.
+// mask_src (optional, bf16 NHWC of dx's shape): dx *= (mask_src > 0 ? 1 : mask_slope) -- the LeakyReLU in front of the layer.
+int vcg_conv2d_nhwc_bf16_dgrad(const vcg_conv_desc* d, const void* dy, const void* wfrag_t, const void* mask_src, float mask_slope,
+                               void* dx, hipStream_t stream) {
+    int rc = check_gdesc(d);
+    if (rc) return rc;
+    VCG_CHECK_PTR(dy); VCG_CHECK_PTR(wfrag_t); VCG_CHECK_PTR(dx);
+    if (d->cin % 32) return VCG_E_UNSUPPORTED;
+    GcParams p{};
+    p.x = dy; p.wf = wfrag_t; p.y = dx; p.mask_src = mask_src; p.mask_slope = mask_slope;
+    p.wbytes = vcg_conv_frag_bf16_bytes(d->kh * d->kw, d->cin, d->cout);
+    p.n = d->n; p.ih = d->oh; p.iw = d->ow; p.kch = d->cout;
+    p.oh = d->h; p.ow = d->w; p.mch = d->cin;
+    p.isy = p.isx = 1;
+    p.mblocks = d->cin / 32;
+    p.act = VCG_ACT_NONE;
+    const int S = d->stride;
+    p.osy = p.osx = S;
+    // dx[iy][ix] = sum over taps with (iy + pad - ky) % S == 0 of W[ky][kx]^T dy[(iy + pad - ky)/S][(ix + pad - kx)/S]:
+    // one launch per output phase (iy % S, ix % S) with that phase's taps
+    for (int py = 0; py < S; ++py)
+        for (int px = 0; px < S; ++px) {
+            p.ooy = py; p.oox = px;
+            p.loh = (d->h - py + S - 1) / S;
+            p.low = (d->w - px + S - 1) / S;
+            p.ntaps = 0;
+            for (int ky = 0; ky < d->kh; ++ky) {
+                if ((py + d->pad_top - ky) % S) continue;
+                for (int kx = 0; kx < d->kw; ++kx) {
+                    if ((px + d->pad_left - kx) % S) continue;
+                    // floor division of a multiple of S
+                    p.taps[p.ntaps++] = GcTap{(short)((py + d->pad_top - ky) / S), (short)((px + d->pad_left - kx) / S), (short)(ky * d->kw + kx), 0};
+                }
+            }
+            if (p.loh <= 0 || p.low <= 0) continue;
+            if (p.ntaps == 0) {   // a phase no tap reaches (k < S): its pixels are zero -- one zero tap keeps the kernel's store path
+                p.taps[0] = GcTap{(short)-30000, (short)-30000, 0, 0};
+                p.ntaps = 1;
+            }
+            rc = launch_gconv(p, stream);
+            if (rc) return rc;
+        }
+    return VCG_OK;
+}
+
+}  // extern "C"

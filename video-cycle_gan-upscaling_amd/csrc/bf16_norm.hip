@@ -44,8 +44,7 @@ __global__ __launch_bounds__(256) void stats_partial_bf16_kernel(const bf16x8* _
         rq[threadIdx.x * 8 + j] = q[j];
     }
     __syncthreads();
-    if (threadIdx.x < c8 * 8) {
-        const int cc = threadIdx.x;        // channel = chunk*8 + j  <->  thread (pl, ch=cc/8) element j=cc%8
+    for (int cc = threadIdx.x; cc < c8 * 8; cc += 256) {      // channel = chunk*8 + j  <->  thread (pl, ch=cc/8) element j=cc%8
         float ts = 0.f, tq = 0.f;
         for (int l = 0; l < npl; ++l) {
             ts += rs[(l * c8 + (cc >> 3)) * 8 + (cc & 7)];
@@ -169,8 +168,7 @@ __global__ __launch_bounds__(256) void norm_bwd_partial_bf16_kernel(const bf16x8
         red[4096 + threadIdx.x * 8 + j] = s3[j];
     }
     __syncthreads();
-    if (threadIdx.x < c8 * 8) {
-        const int cc = threadIdx.x;
+    for (int cc = threadIdx.x; cc < c8 * 8; cc += 256) {
         float t1 = 0.f, t2 = 0.f, t3 = 0.f;
         for (int l = 0; l < npl; ++l) {
             const int o = (l * c8 + (cc >> 3)) * 8 + (cc & 7);
@@ -282,7 +280,7 @@ int vcg_norm_stats_bf16(const void* x, int n, int c, int hw, int mode, float* me
                         hipStream_t stream) {
     VCG_CHECK_PTR(x); VCG_CHECK_PTR(mean); VCG_CHECK_PTR(var); VCG_CHECK_PTR(ws);
     if (n <= 0 || c <= 0 || hw <= 0) return VCG_E_SHAPE;
-    if (c % 8 != 0 || c > 256) return VCG_E_UNSUPPORTED;
+    if (c % 8 != 0 || c > 2048) return VCG_E_UNSUPPORTED;
     if (ws_bytes < vcg_norm_stats_bf16_workspace_bytes(n, c, hw, mode)) return VCG_E_WORKSPACE;
     const long gp = mode == VCG_NORM_INSTANCE ? hw : (long)n * hw;
     const int groups = mode == VCG_NORM_INSTANCE ? n : 1;
@@ -298,7 +296,7 @@ int vcg_norm_act_fwd_bf16(const void* x, int n, int c, int hw, const float* scal
                           float alpha, const float* prelu_alpha, const void* residual, void* y, hipStream_t stream) {
     VCG_CHECK_PTR(x); VCG_CHECK_PTR(scale); VCG_CHECK_PTR(shift); VCG_CHECK_PTR(y);
     if (n <= 0 || c <= 0 || hw <= 0) return VCG_E_SHAPE;
-    if (c % 8 != 0 || c > 256) return VCG_E_UNSUPPORTED;
+    if (c % 8 != 0 || c > 2048) return VCG_E_UNSUPPORTED;
     if (act == VCG_ACT_PRELU && !prelu_alpha) return VCG_E_NULL;
     if (act == VCG_ACT_TANH) return VCG_E_UNSUPPORTED;
     const int bpi = ceil_div(hw, APB);
@@ -319,7 +317,7 @@ int vcg_norm_act_bwd_bf16(const void* x, const void* dy, int n, int c, int hw, i
                           void* dx, float* dgamma, float* dbeta, float* dprelu_alpha, void* ws, size_t ws_bytes, hipStream_t stream) {
     VCG_CHECK_PTR(x); VCG_CHECK_PTR(dy); VCG_CHECK_PTR(mean); VCG_CHECK_PTR(invstd); VCG_CHECK_PTR(dx); VCG_CHECK_PTR(ws);
     if (n <= 0 || c <= 0 || hw <= 0) return VCG_E_SHAPE;
-    if (c % 8 != 0 || c > 256 || act == VCG_ACT_TANH) return VCG_E_UNSUPPORTED;
+    if (c % 8 != 0 || c > 2048 || act == VCG_ACT_TANH) return VCG_E_UNSUPPORTED;
     if (act == VCG_ACT_PRELU && !prelu_alpha) return VCG_E_NULL;
     if (ws_bytes < vcg_norm_act_bwd_bf16_workspace_bytes(n, c, hw, mode)) return VCG_E_WORKSPACE;
     const int inst = mode == VCG_NORM_INSTANCE;

@@ -594,6 +594,82 @@ class Conv3x3Bf16(Layer):
         return dx
 
 
+class Conv2DBf16(Conv2D):
+    """keras.layers.Conv2D on bf16 NHWC activations, any of the discriminators' shapes (3x3 / 4x4 / 5x5, stride 1-3, channel
+    counts that are multiples of 32): forward and data gradient on vcg_conv2d_nhwc_bf16_* (weights re-laid out as MFMA operand
+    fragments after every optimizer step), weight gradient on vcg_conv2d_nhwc_bf16_wgrad; fp32 master weights, gradients and
+    bias.  Same parameter names / layouts as Conv2D: a bf16 model exchanges weights with the fp32 one and with the reference."""
+
+    def __init__(self, name, cin, cout, k, stride=1, padding="same", act=L.ACT_NONE, alpha=0.0):
+        if act != L.ACT_NONE:
+            raise NotImplementedError("Conv2DBf16 carries no fused activation (the layers it serves are followed by a normalisation)")
+        if cin % 32 or cout % 32:
+            raise NotImplementedError("Conv2DBf16 needs channel counts that are multiples of 32")
+        super().__init__(name, cin, cout, k, stride, padding, act, alpha)
+        self._wf = self._wd = None
+        self._pvalid = False
+
+    def refresh(self):
+        super().refresh()
+        self._pvalid = False
+
+    def _packed(self):
+        rt = self.rt
+        t = self.k * self.k
+        if self._wf is None:
+            self._wf = torch.empty(t * self.cin * self.cout, dtype=torch.bfloat16, device=rt.device)
+            self._wd = torch.empty(t * self.cin * self.cout, dtype=torch.bfloat16, device=rt.device)
+        if not self._pvalid:
+            w = self.ps[self.name + "/kernel"].data_ptr()
+            L.check(rt.lib.vcg_pack_conv_frag_bf16(w, t, self.cout, self.cin, 0, self._wf.data_ptr(), rt.stream), "pack fwd")
+            L.check(rt.lib.vcg_pack_conv_frag_bf16(w, t, self.cin, self.cout, 1, self._wd.data_ptr(), rt.stream), "pack dgrad")
+            self._pvalid = True
+        return self._wf, self._wd
+
+    def forward(self, x, residual=None, tag=None):
+        rt = self.rt
+        n, h, w, _ = x.shape
+        d = self.desc(n, h, w)
+        wf, _ = self._packed()
+        y = torch.empty(n, d.oh, d.ow, self.cout, dtype=torch.bfloat16, device=rt.device)
+        with Timed(rt, tag):
+            L.check(rt.lib.vcg_conv2d_nhwc_bf16_fwd(ctypes.byref(d), x.data_ptr(), wf.data_ptr(), self.ps[self.name + "/bias"].data_ptr(),
+                                                    L.ACT_NONE, 0.0, y.data_ptr(), rt.stream), "vcg_conv2d_nhwc_bf16_fwd[%s]" % self.name)
+        return y, (x, None, d)
+
+    def backward(self, ctx, dy, need_dx=True, param_grads=True, which=0, dx_residual=None, tag=None):
+        rt = self.rt
+        x, _, d = ctx
+        if param_grads:
+            ws, wsn = rt.workspace(rt.lib.vcg_conv2d_nhwc_bf16_wgrad_workspace_bytes(ctypes.byref(d)))
+            with Timed(rt, tag and tag + "_wgrad"):
+                L.check(rt.lib.vcg_conv2d_nhwc_bf16_wgrad(ctypes.byref(d), x.data_ptr(), dy.data_ptr(),
+                                                          self.ps.grad(self.name + "/kernel", which).data_ptr(),
+                                                          self.ps.grad(self.name + "/bias", which).data_ptr(), ws, wsn, rt.stream),
+                        "vcg_conv2d_nhwc_bf16_wgrad[%s]" % self.name)
+        if not need_dx:
+            return None
+        _, wd = self._packed()
+        dx = torch.empty_like(x)
+        with Timed(rt, tag and tag + "_dgrad"):
+            L.check(rt.lib.vcg_conv2d_nhwc_bf16_dgrad(ctypes.byref(d), dy.data_ptr(), wd.data_ptr(), None, 0.0, dx.data_ptr(), rt.stream),
+                    "vcg_conv2d_nhwc_bf16_dgrad[%s]" % self.name)
+        return dx
+
+
+def bf16_to_f32(rt, x):
+    """flat precision change, shape kept (Flatten of NHWC is its memory order)"""
+    y = rt.empty(*x.shape)
+    L.check(rt.lib.vcg_bf16_to_f32(x.data_ptr(), y.data_ptr(), x.numel(), rt.stream), "vcg_bf16_to_f32")
+    return y
+
+
+def f32_to_bf16(rt, x):
+    y = torch.empty(*x.shape, dtype=torch.bfloat16, device=rt.device)
+    L.check(rt.lib.vcg_f32_to_bf16(x.data_ptr(), y.data_ptr(), x.numel(), rt.stream), "vcg_f32_to_bf16")
+    return y
+
+
 class ConvT3x3Bf16(ConvT2D):
     """upsampling_block (model.py:70-75) with bf16 activations: Conv2DTranspose(3, strides 2) 64 -> 64m + bias + LeakyReLU forward on
     vcg_conv_transpose2d_bf16_fwd (bf16 NHWC in and out).  Backward takes the gradient in front of the activation (the bf16 data

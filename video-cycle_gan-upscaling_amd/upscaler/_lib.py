@@ -104,6 +104,17 @@ SIGNATURES = {
     "vcg_conv9x9_from3_bf16_fwd": (c_int, [_D, _P, _P, _P, _P, _P, _P]),
     "vcg_pack_final9x9_bf16": (c_int, [_P, _P, _P]),
     "vcg_conv9x9_to3_bf16_fwd": (c_int, [_D, _P, _P, _P, c_int, _P, _P]),
+    # generic bf16 NHWC convolution
+    "vcg_conv_frag_bf16_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "vcg_pack_conv_frag_bf16": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P]),
+    "vcg_conv2d_nhwc_bf16_fwd": (c_int, [_D, _P, _P, _P, c_int, c_float, _P, _P]),
+    "vcg_conv2d_nhwc_bf16_dgrad": (c_int, [_D, _P, _P, _P, c_float, _P, _P]),
+    "vcg_conv2d_nhwc_bf16_wgrad_workspace_bytes": (c_size_t, [_D]),
+    "vcg_conv2d_nhwc_bf16_wgrad": (c_int, [_D, _P, _P, _P, _P, _P, c_size_t, _P]),
+    "vcg_conv_transpose2d_nhwc_bf16_wgrad_workspace_bytes": (c_size_t, [_D]),
+    "vcg_conv_transpose2d_nhwc_bf16_wgrad": (c_int, [_D, _P, _P, _P, _P, c_size_t, _P]),
+    "vcg_bf16_to_f32": (c_int, [_P, _P, c_size_t, _P]),
+    "vcg_f32_to_bf16": (c_int, [_P, _P, c_size_t, _P]),
 }
 
 _lib = None
