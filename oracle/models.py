@@ -144,7 +144,9 @@ def upscaler_orig_forward(w, x_nhwc, training, res_block_num, upscale_factor, ta
         m = tap(n + "/final_add", st(gen + m))
     m = tconv(m, "prefinal/conv2d")
     m = rg(bn(m, "prefinal/batch_norm"))
-    m = tap("prefinal/tanh", rf(skip + m))                        # Add misnamed in model.py:285
+    # Add misnamed in model.py:285.  'bf16+tail': the up-sampling block's data gradient is produced in bf16, so BOTH branches of
+    # the add (the long skip too) see the rounded gradient
+    m = tap("prefinal/tanh", (K.bf16_store if tail_bf16 else rf)(skip + m))
     trf = K.bf16_round_fwd if tail_bf16 else (lambda v: v)
     trg = K.bf16_round_grad if tail_bf16 else (lambda v: v)
     for i in range(int(math.log(upscale_factor, 2))):
@@ -189,9 +191,13 @@ def init_discriminator_512(input_shape, variant="simple", seed=11):
     return w
 
 
-def discriminator_512_forward(w, x_nhwc, training, activation="none", taps=None):
-    """make_discriminator_simple_512 / _thin_512 forward: [N,H,W,3] -> ([N,1], bn_updates)."""
+def discriminator_512_forward(w, x_nhwc, training, activation="none", taps=None, bf16=False):
+    """make_discriminator_simple_512 / _thin_512 forward: [N,H,W,3] -> ([N,1], bn_updates).  ``bf16`` marks the tensors the
+    product's ``dtype='bf16'`` mode stores in bf16 (blocks 2..9: convolution and normalisation outputs, values and gradients; bf16
+    copies of the fp32 master kernels) -- keras_ops.bf16_*."""
     upd = OrderedDict()
+    st = K.bf16_store if bf16 else (lambda v: v)
+    rf = K.bf16_round_fwd if bf16 else (lambda v: v)
 
     def bn(x, name):
         y, mm, mv = K.batchnorm(x, w[name + "/gamma"], w[name + "/beta"], w[name + "/moving_mean"],
@@ -204,9 +210,12 @@ def discriminator_512_forward(w, x_nhwc, training, activation="none", taps=None)
     i = 1
     while ("discriminator/block_%d/Conv2d/kernel" % i) in w:
         n = "discriminator/block_%d" % i
-        m = K.conv2d(m, w[n + "/Conv2d/kernel"], w[n + "/Conv2d/bias"], 1 if i == 1 else 2, "same")
-        m = bn(m, n + "/BatchNorm")
-        m = K.leaky_relu(m, 0.1)
+        if i == 1:
+            m = K.conv2d(m, w[n + "/Conv2d/kernel"], w[n + "/Conv2d/bias"], 1, "same")
+            m = st(K.leaky_relu(bn(m, n + "/BatchNorm"), 0.1))            # fp32 block; its output enters the bf16 layout
+        else:
+            m = st(K.conv2d(m, rf(w[n + "/Conv2d/kernel"]), w[n + "/Conv2d/bias"], 2, "same"))
+            m = st(K.leaky_relu(bn(m, n + "/BatchNorm"), 0.1))
         if taps is not None:
             taps[n + "/LeakyReLU"] = m
         i += 1
@@ -235,13 +244,19 @@ def init_discriminator_patchgan_70(input_shape, norm="instance", seed=11):
     return w
 
 
-def discriminator_patchgan_70_forward(w, x_nhwc, training, activation="none", norm="instance", taps=None):
-    """70x70 PatchGAN: [N,H,W,3] -> ([N,H',W',1], bn_updates); 512x512 -> 62x62."""
+def discriminator_patchgan_70_forward(w, x_nhwc, training, activation="none", norm="instance", taps=None, bf16=False):
+    """70x70 PatchGAN: [N,H,W,3] -> ([N,H',W',1], bn_updates); 512x512 -> 62x62.  ``bf16``: storage roundings of the product's
+    ``dtype='bf16'`` mode (the three normalised blocks)."""
     upd = OrderedDict()
+    st = K.bf16_store if bf16 else (lambda v: v)
+    rf = K.bf16_round_fwd if bf16 else (lambda v: v)
     m = x_nhwc.permute(0, 3, 1, 2)
     for i, (f, s, kind) in enumerate(_PATCH_SPEC):
         n = "discriminator/block_%d" % (i + 1)
-        m = K.conv2d(m, w[n + "/Conv2d/kernel"], w[n + "/Conv2d/bias"], s, 1)
+        if kind == "norm":
+            m = st(K.conv2d(m, rf(w[n + "/Conv2d/kernel"]), w[n + "/Conv2d/bias"], s, 1))
+        else:
+            m = K.conv2d(m, w[n + "/Conv2d/kernel"], w[n + "/Conv2d/bias"], s, 1)
         if kind == "norm":
             if norm == "instance":
                 m = K.instancenorm(m)
@@ -253,6 +268,8 @@ def discriminator_patchgan_70_forward(w, x_nhwc, training, activation="none", no
                     upd[bnn + "/moving_mean"], upd[bnn + "/moving_variance"] = mm, mv
         if kind != "last":
             m = K.leaky_relu(m, 0.2)
+            if kind == "norm" or i == 0:
+                m = st(m)                 # block 1's output enters the bf16 layout; the normalised blocks' outputs live in it
             if taps is not None:
                 taps[n + "/LeakyReLU"] = m
     m = K.head_activation(m, activation)

@@ -621,3 +621,136 @@ def test_generic_conv_bf16_fwd_dgrad_wgrad(rt, cin, cout, k, stride, padding, n,
     g1 = ps.grad("c/kernel").clone()
     layer.backward(ctx, _to_nhwc_bf16(rt, dy.to(rt.device)), False, True, 0)
     assert torch.equal(g1, ps.grad("c/kernel"))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# bf16 discriminators and the all-bf16 train step (BASELINE.json configs C3 / C4)
+# ---------------------------------------------------------------------------------------------------------------
+def _l2(a, b, floor=0.0):
+    return float((a - b).norm() / (b.norm() + floor))
+
+
+@pytest.mark.parametrize("kind", ["patch", "simple", "thin"])
+def test_bf16_discriminator_forward_and_gradients(rt, kind):
+    """make_discriminator_*(..., dtype='bf16'): training-mode forward, input gradient and every parameter gradient against the
+    fp64 oracle evaluated with the same storage roundings; yardstick per tensor = that tensor's own distance between the fp32
+    and fp64 runs of the same emulation (bound 2.5x, floor 1e-2; numerically-zero gradients excluded and reported)."""
+    from oracle import models as M
+    from upscaler import model as PM, _engine as E
+    n, hw = 4, 64
+    if kind == "patch":
+        D = PM.make_discriminator_patchgan_70((hw, hw, 3), dtype="bf16")
+        dfw = lambda w, x, b: M.discriminator_patchgan_70_forward(w, x, True, bf16=b)[0]
+    else:
+        D = (PM.make_discriminator_simple_512 if kind == "simple" else PM.make_discriminator_thin_512)((hw, hw, 3), dtype="bf16")
+        dfw = lambda w, x, b: M.discriminator_512_forward(w, x, True, bf16=b)[0]
+    wd = _randomize_bn(D, 7)
+    x = (np.random.RandomState(3).randint(0, 256, (n, hw, hw, 3)) / 127.5 - 1).astype(np.float32)
+    coef = np.random.RandomState(4).randn(*([n] + list(D.output_shape[1:]))).astype(np.float32)
+
+    def oracle(bf, dt):
+        leaf = M.to_torch(wd, dt, requires_grad=True)
+        xi = torch.tensor(x, dtype=dt, requires_grad=True)
+        y = dfw(leaf, xi, bf)
+        loss = (y * torch.tensor(coef, dtype=dt).view(*y.shape)).sum()
+        names = [k for k, v in leaf.items() if v.requires_grad]
+        gs = torch.autograd.grad(loss, [leaf[k] for k in names] + [xi])
+        return y.detach().double(), dict(zip(names, [g.double() for g in gs[:-1]])), gs[-1].double()
+    yr, gref, dxr = oracle(True, torch.float64)
+    y32, g32, dx32 = oracle(True, torch.float32)
+    yp, _, _ = oracle(False, torch.float64)
+    xd = E.to_device_nchw(rt, x)
+    y, tape = D.forward(xd, True, True)
+    dy = E.to_device_nchw(rt, coef.reshape(n, *yr.shape[1:])) if y.dim() == 4 else torch.tensor(coef, device=rt.device).view(*y.shape).contiguous()
+    dx = D.backward(tape, dy, True, True, 0)
+    yd = (E.to_nhwc(rt, y) if y.dim() == 4 else y).cpu().double()
+    e_y, e32_y = _l2(yd, yr), _l2(y32, yr)
+    e_dx, e32_dx = _l2(E.to_nhwc(rt, dx).cpu().double(), dxr), _l2(dx32, dxr)
+    gmax = max(float(g.abs().max()) for g in gref.values())
+    worst = 0.0
+    for k, b in gref.items():
+        a = D.ps.grad(k).cpu().double()
+        floor = 1e-4 * gmax * b.numel() ** 0.5
+        real = float(b.norm()) >= floor
+        e, e32 = _l2(a, b, floor), _l2(g32[k], b, floor)
+        report("    bf16 D[%s] %-44s |g|2=%.2e rel L2 err=%.2e (oracle fp32-vs-fp64, same storage: %.2e)%s"
+               % (kind, k, float(b.norm()), e, e32, "" if real else "   [zero gradient: excluded]"))
+        if real:
+            worst = max(worst, e)
+            assert e < max(1e-2, 2.5 * e32), (k, e, e32)
+    report("bf16 discriminator %s: output err=%.2e (yardstick %.2e; vs un-rounded oracle %.2e)  input-gradient err=%.2e (yardstick %.2e)  worst parameter gradient=%.2e"
+           % (kind, e_y, e32_y, _l2(yd, yp), e_dx, e32_dx, worst))
+    assert e_y < max(2e-3, 2.5 * e32_y) and e_dx < max(1e-2, 2.5 * e32_dx)
+
+
+def test_all_bf16_train_step_matches_emulating_oracle(rt):
+    """C3's arithmetic at C1's frame size: generator 'bf16+tail' and PatchGAN dtype='bf16' through two loop-body iterations
+    (train_gan3.py:346-354) against the fp64 oracle with the same storage roundings in G and D.  Losses of the first iteration
+    to max(2e-3, 3x the oracle's own fp32-vs-fp64 distance); second iteration (after one primed Adam update each) to
+    max(1e-2, 3x)."""
+    from oracle import models as M, train as T
+    from upscaler import model as PM, _lib as L
+    res, bs, h = 2, 4, 64
+    G = PM.make_upscaler_orig((2 * h, 2 * h, 3), kernel_size=3, upscale_factor=2, res_block_num=res, seed=7, trunk_dtype="bf16+tail")
+    D = PM.make_discriminator_patchgan_70((2 * h, 2 * h, 3), seed=11, dtype="bf16")
+    gw, dw = _randomize_bn(G, 5), _randomize_bn(D, 6)
+    gf = lambda w, x, t: M.upscaler_orig_forward(w, x, t, res, 2, trunk_bf16=True, tail_bf16=True)
+    df = lambda w, x, t: M.discriminator_patchgan_70_forward(w, x, t, bf16=True)
+
+    def mk(dt):
+        return T.GanOracle(gf, M.to_torch(gw, dt), df, M.to_torch(dw, dt), wiring="gan2", content="mse", losses="wass",
+                           discriminator_loss_weight=1e-2, adam_v0=1.0)
+    orc, orc32 = mk(torch.float64), mk(torch.float32)
+    _, _, gan_train = PM.make_and_compile_gan2(G, D, (h, h, 3), (2 * h, 2 * h, 3), "mse", 1.0, lambda: PM.WassersteinLosses(), 1e-2,
+                                               optimizer=PM.Adam())
+    tr = gan_train.trainer
+    for s in (tr.g_slots, tr.d_slots):
+        L.check(rt.lib.vcg_fill(s.v.data_ptr(), s.v.numel(), 1.0, rt.stream), "vcg_fill")
+    rng = np.random.RandomState(8)
+    for it in range(2):
+        lr = (rng.randint(0, 256, (bs, h, h, 3)) / 127.5 - 1).astype(np.float32)
+        hr = (rng.randint(0, 256, (bs, 2 * h, 2 * h, 3)) / 127.5 - 1).astype(np.float32)
+        got = gan_train.train_step(lr, hr)
+        ref = orc.train_step(torch.tensor(lr, dtype=torch.float64), torch.tensor(hr, dtype=torch.float64))
+        r32 = orc32.train_step(torch.tensor(lr), torch.tensor(hr))
+        scale = max(abs(v) for v in ref) + 1e-6
+        for name, a, b, c in zip(("disc", "gan", "content", "adv"), got, ref, r32):
+            err, e32 = abs(a - b) / scale, abs(c - b) / scale
+            report("all-bf16 train step it=%d loss_%s got=%.6g ref=%.6g err=%.1e (oracle fp32-vs-fp64, same storage: %.1e)" % (it, name, a, b, err, e32))
+            assert err < max(2e-3 if it == 0 else 1e-2, 3 * e32), (it, name, a, b, c)
+
+
+def test_all_bf16_train_step_at_c4_frame_size(rt):
+    """BASELINE.json config C4 in its stated arithmetic: 540x960 -> 1080x1920 frames, generator 'bf16+tail' + PatchGAN 'bf16',
+    one whole train step at batch 1 (finite losses, close to the fp32 product's on the same frames and weights), and the
+    inference output of a 32-row band against the oracle (rows far from the band edges, as in
+    test_model_gpu.py::test_c4_frame_size_train_step_runs)."""
+    from oracle import models as M
+    from upscaler import model as PM
+    h, w = 540, 960
+
+    def build(bf):
+        G = PM.make_upscaler_orig((2 * h, 2 * w, 3), kernel_size=3, upscale_factor=2, res_block_num=2, seed=7, trunk_dtype="bf16+tail" if bf else "fp32")
+        D = PM.make_discriminator_patchgan_70((2 * h, 2 * w, 3), seed=11, dtype="bf16" if bf else "fp32")
+        _, _, gan = PM.make_and_compile_gan2(G, D, (h, w, 3), (2 * h, 2 * w, 3), "mse", 1.0, lambda: PM.WassersteinLosses(), 1e-5, optimizer=PM.Adam())
+        return G, D, gan
+    rng = np.random.RandomState(9)
+    lr = (rng.randint(0, 256, (1, h, w, 3)) / 127.5 - 1).astype(np.float32)
+    hr = (rng.randint(0, 256, (1, 2 * h, 2 * w, 3)) / 127.5 - 1).astype(np.float32)
+    Gb, Db, ganb = build(True)
+    lb = ganb.train_step(lr, hr)
+    predb = Gb.predict(lr)                       # after the step: the same weights the oracle band run gets
+    gw = M.to_torch(Gb.get_weights_dict(), torch.float64)
+    band = lr[:, 262:294]
+    with torch.no_grad():
+        ref, _ = M.upscaler_orig_forward(gw, torch.tensor(band, dtype=torch.float64), False, 2, 2)
+    inner = slice(2 * 14, 2 * 18)
+    e = rel_err(predb[:, 2 * 262 + inner.start:2 * 262 + inner.stop], ref[:, inner].numpy())
+    Gf, Df, ganf = build(False)
+    lf = ganf.train_step(lr, hr)
+    report("C4 frame size, all-bf16 step: losses %s (fp32 product %s)  band parity of predict vs fp64 oracle err=%.2e"
+           % (["%.5g" % v for v in lb], ["%.5g" % v for v in lf], e))
+    assert all(np.isfinite(v) for v in lb)
+    assert e < 2e-2                                # bf16 storage through 2 blocks + tail (3e-2 bound of the 9-block inference test)
+    for a, b in zip(lb, lf):
+        assert abs(a - b) < 3e-2 * (max(abs(v) for v in lf) + 1e-6), (lb, lf)

@@ -672,16 +672,16 @@ def f32_to_bf16(rt, x):
 
 class ConvT3x3Bf16(ConvT2D):
     """upsampling_block (model.py:70-75) with bf16 activations: Conv2DTranspose(3, strides 2) 64 -> 64m + bias + LeakyReLU forward on
-    vcg_conv_transpose2d_bf16_fwd (bf16 NHWC in and out).  Backward takes the gradient in front of the activation (the bf16 data
-    gradient of final/conv applies the LeakyReLU derivative itself) and, until the bf16 transposed-convolution gradients exist,
-    runs the fp32 kernels on fp32 NCHW copies of the bf16 operands (exact conversions) with the bf16-rounded kernel -- the weights
-    the forward pass used."""
+    vcg_conv_transpose2d_bf16_fwd (bf16 NHWC in and out).  Backward takes the gradient dz in front of the activation (the bf16 data
+    gradient of final/conv applies the LeakyReLU derivative itself): data gradient = the stride-2 convolution of dz with the kernel
+    read as (in = out-channels, out = in-channels) on vcg_conv2d_nhwc_bf16_fwd, weight gradient on
+    vcg_conv_transpose2d_nhwc_bf16_wgrad, bias gradient = per-channel sum of dz (vcg_norm_stats_bf16's shifted sums)."""
 
     def __init__(self, name, cin, cout, k, act=L.ACT_NONE, alpha=0.0):
         if k != 3 or cin != 64 or cout % 64:
             raise NotImplementedError("the bf16 transposed convolution is instantiated for 3x3, 64 -> 64m channels")
         super().__init__(name, cin, cout, k, act, alpha)
-        self._wp = self._wr = None
+        self._wp = self._wg = None
         self._pvalid = False
 
     def refresh(self):
@@ -692,12 +692,14 @@ class ConvT3x3Bf16(ConvT2D):
         rt = self.rt
         if self._wp is None:
             self._wp = torch.empty(9, self.cout, self.cin, dtype=torch.bfloat16, device=rt.device)
+            self._wg = torch.empty(9 * self.cout * self.cin, dtype=torch.bfloat16, device=rt.device)
         if not self._pvalid:
             w = self.ps[self.name + "/kernel"]
             L.check(rt.lib.vcg_pack_conv_kernel_bf16(w.data_ptr(), 9, self.cout, self.cin, 0, 0, self._wp.data_ptr(), rt.stream), "pack convT")
-            self._wr = w.to(torch.bfloat16).to(torch.float32)        # the kernel as the forward pass saw it (a cast, fp32 layout)
+            # data gradient: Keras' (kh,kw,out,in) kernel is a Conv2D kernel (kh,kw,in'=out,out'=in) of the convolution dz -> dx
+            L.check(rt.lib.vcg_pack_conv_frag_bf16(w.data_ptr(), 9, self.cin, self.cout, 0, self._wg.data_ptr(), rt.stream), "pack convT dgrad")
             self._pvalid = True
-        return self._wp, self._wr
+        return self._wp, self._wg
 
     def forward(self, x, tag=None):
         rt = self.rt
@@ -712,23 +714,31 @@ class ConvT3x3Bf16(ConvT2D):
         return y, (x, y, d)
 
     def backward(self, ctx, dz, need_dx=True, param_grads=True, which=0, tag=None):
-        """dz: bf16 NHWC gradient in front of the LeakyReLU.  Returns dx as fp32 NCHW."""
-        rt = self.rt
+        """dz: bf16 NHWC gradient in front of the LeakyReLU.  Returns dx as bf16 NHWC."""
+        rt, lib = self.rt, self.rt.lib
         x, _, d = ctx
-        x32, dz32 = from_bf16_nhwc(rt, x), from_bf16_nhwc(rt, dz)
-        _, wr = self._packed()
+        _, wg = self._packed()
         if param_grads:
-            ws, wsn = rt.workspace(rt.lib.vcg_conv_transpose2d_wgrad_workspace_bytes(ctypes.byref(d)))
+            ws, wsn = rt.workspace(lib.vcg_conv_transpose2d_nhwc_bf16_wgrad_workspace_bytes(ctypes.byref(d)))
             with Timed(rt, tag and tag + "_wgrad"):
-                L.check(rt.lib.vcg_conv_transpose2d_wgrad(ctypes.byref(d), x32.data_ptr(), dz32.data_ptr(), self.ps.grad(self.name + "/kernel", which).data_ptr(),
-                                                          self.ps.grad(self.name + "/bias", which).data_ptr(), ws, wsn, rt.stream),
-                        "vcg_conv_transpose2d_wgrad[%s]" % self.name)
+                L.check(lib.vcg_conv_transpose2d_nhwc_bf16_wgrad(ctypes.byref(d), x.data_ptr(), dz.data_ptr(),
+                                                                 self.ps.grad(self.name + "/kernel", which).data_ptr(), ws, wsn, rt.stream),
+                        "vcg_conv_transpose2d_nhwc_bf16_wgrad[%s]" % self.name)
+            # bias gradient: sum of dz over (n, h, w) = its per-channel mean x count
+            hw = d.oh * d.ow
+            mean, var = rt.empty(self.cout), rt.empty(self.cout)
+            ws, wsn = rt.workspace(lib.vcg_norm_stats_bf16_workspace_bytes(d.n, self.cout, hw, L.NORM_BATCH))
+            L.check(lib.vcg_norm_stats_bf16(dz.data_ptr(), d.n, self.cout, hw, L.NORM_BATCH, mean.data_ptr(), var.data_ptr(), ws, wsn, rt.stream),
+                    "vcg_norm_stats_bf16[%s]" % self.name)
+            axpby(rt, mean, self.ps.grad(self.name + "/bias", which), float(d.n * hw), 0.0)
         if not need_dx:
             return None
-        dx = rt.empty(d.n, self.cin, d.h, d.w)
+        # dx[ci][i] = sum dz[co][2i + k - crop] W[k][co][ci]: a stride-2 convolution over dz (pad = the crop)
+        dd = L.ConvDesc(d.n, self.cout, d.oh, d.ow, self.cin, d.h, d.w, self.k, self.k, 2, d.pad_top, d.pad_left)
+        dx = torch.empty_like(x)
         with Timed(rt, tag and tag + "_dgrad"):
-            L.check(rt.lib.vcg_conv_transpose2d_dgrad(ctypes.byref(d), dz32.data_ptr(), wr.data_ptr(), dx.data_ptr(), None, rt.stream),
-                    "vcg_conv_transpose2d_dgrad[%s]" % self.name)
+            L.check(lib.vcg_conv2d_nhwc_bf16_fwd(ctypes.byref(dd), dz.data_ptr(), wg.data_ptr(), None, L.ACT_NONE, 0.0, dx.data_ptr(), rt.stream),
+                    "vcg_conv2d_nhwc_bf16_fwd[%s dgrad]" % self.name)
         return dx
 
 

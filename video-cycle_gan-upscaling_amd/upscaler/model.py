@@ -480,7 +480,8 @@ class UpscalerOrig(Model):
         rt = self.rt
         tape = list(tape)
         if self.tail_bf16:
-            # final/conv's bf16 data gradient applies the up-sampling block's LeakyReLU derivative; the block returns fp32 NCHW
+            # final/conv's bf16 data gradient applies the up-sampling block's LeakyReLU derivative; the block's own gradients run
+            # on the bf16 kernels and hand back bf16 NHWC, which is what the trunk's backward consumes
             d = self.c_fin.backward(tape.pop(), dy, True, True, which, tag="final_conv", input_lrelu_slope=self.ups[-1].alpha)
             d = self.ups[-1].backward(tape.pop(), d, True, True, which, tag="convt")
         else:
@@ -488,9 +489,12 @@ class UpscalerOrig(Model):
             for u in reversed(self.ups):
                 d = u.backward(tape.pop(), d, True, True, which, tag="convt")
         # s = skip + BN(conv(h)):  d flows to both
-        dskip = d
-        if self.trunk_dtype == "bf16":
-            d = E.to_bf16_nhwc(rt, d)
+        if self.tail_bf16:
+            dskip = E.from_bf16_nhwc(rt, d)        # the long skip joins the fp32 initial/prelu output
+        else:
+            dskip = d
+            if self.trunk_dtype == "bf16":
+                d = E.to_bf16_nhwc(rt, d)
         d = self.n_pre.backward(tape.pop(), d, True, which)
         d = self.c_pre.backward(tape.pop(), d, True, True, which, tag="trunk_conv")
         for (c1, n1, c2, n2) in reversed(self.blocks):
@@ -510,10 +514,18 @@ class UpscalerOrig(Model):
 
 class DiscriminatorStack(Model):
     """Strided-conv critic with Flatten/Dense head: make_discriminator_simple_512 (model.py:836-896) and
-    make_discriminator_thin_512 (:901-961)."""
+    make_discriminator_thin_512 (:901-961).
 
-    def __init__(self, input_shape, filters, activation, seed, name):
+    ``dtype='bf16'`` (BASELINE.json configs C3/C4): blocks 2..9 -- the stride-2 convolutions that hold 97 % of the critic's
+    FLOPs -- and their BatchNormalization / LeakyReLU keep their activations in bf16 NHWC (Conv2DBf16 / NormActBf16: fp32
+    accumulation, statistics, master weights and gradients); block 1 (3 input channels) and the Dense head stay fp32.  Flatten of
+    the NHWC tensor is its memory order, so entering the head is a flat bf16 -> fp32 conversion."""
+
+    def __init__(self, input_shape, filters, activation, seed, name, dtype="fp32"):
         super().__init__(name, input_shape, seed)
+        if dtype not in ("fp32", "bf16"):
+            raise ValueError(dtype)
+        self.dtype = dtype
         self.activation = activation
         self.head = L.HEAD_KINDS.get(activation, L.HEAD_NONE)     # any other string: no activation, like the reference's if/elif chain
         self.convs = []
@@ -522,8 +534,11 @@ class DiscriminatorStack(Model):
         for i, f in enumerate(filters):
             n = "discriminator/block_%d" % (i + 1)
             s = 1 if i == 0 else 2
-            self.convs.append((self._add(E.Conv2D(n + "/Conv2d", cin, f, 3, s)),
-                               self._add(E.NormAct(n + "/BatchNorm", f, "batch", L.ACT_LRELU, 0.1))))
+            bf = dtype == "bf16" and i > 0
+            conv = E.Conv2DBf16 if bf else E.Conv2D
+            norm = E.NormActBf16 if bf else E.NormAct
+            self.convs.append((self._add(conv(n + "/Conv2d", cin, f, 3, s)),
+                               self._add(norm(n + "/BatchNorm", f, "batch", L.ACT_LRELU, 0.1))))
             if s == 2:
                 h, w = -(-h // 2), -(-w // 2)
             cin = f
@@ -545,13 +560,21 @@ class DiscriminatorStack(Model):
     def forward(self, x, training, update_moving=True):
         if tuple(x.shape[2:]) != tuple(self._in_shape[:2]):
             raise ValueError("discriminator built for %s, got %s" % (self._in_shape[:2], tuple(x.shape[2:])))
+        rt = self.rt
+        bf = self.dtype == "bf16"
         tape = []
         h = x
         for i, (cv, na) in enumerate(self.convs):
+            if bf and i == 1:
+                h = E.to_bf16_nhwc(rt, h)
             h, a = cv.forward(h, tag="d_conv"); tape.append(a)
             h, a = na.forward(h, training, update_moving=update_moving); tape.append(a)
-        hf = E.to_nhwc(self.rt, h)                     # Flatten of NHWC is (h,w,c)-major (Appendix A)
-        tape.append(tuple(h.shape))
+        if bf and len(self.convs) > 1:
+            tape.append(tuple(h.shape))
+            hf = E.bf16_to_f32(rt, h)                  # Flatten of NHWC is (h,w,c)-major (Appendix A) = this tensor's memory order
+        else:
+            hf = E.to_nhwc(rt, h)
+            tape.append(tuple(h.shape))
         h = hf.view(hf.shape[0], -1)
         for dn, bn in ((self.d1, self.b1), (self.d2, self.b2)):
             h, a = dn.forward(h); tape.append(a)
@@ -564,6 +587,7 @@ class DiscriminatorStack(Model):
 
     def backward(self, tape, dy, need_dx=False, param_grads=True, which=0):
         rt = self.rt
+        bf = self.dtype == "bf16" and len(self.convs) > 1
         tape = list(tape)
         if self.head:
             dy = E.head_act_bwd(rt, tape.pop(), dy, self.head)
@@ -571,24 +595,34 @@ class DiscriminatorStack(Model):
         for dn, bn in ((self.d2, self.b2), (self.d1, self.b1)):
             d = bn.backward(tape.pop(), d, param_grads, which)
             d = dn.backward(tape.pop(), d, True, param_grads, which)
-        n, c, h, w = tape.pop()
-        dn_ = rt.empty(n, c, h, w)
-        L.check(rt.lib.vcg_nhwc_to_nchw(d.data_ptr(), dn_.data_ptr(), n, h, w, c, rt.stream), "vcg_nhwc_to_nchw")
-        d = dn_
+        shp = tape.pop()
+        if bf:
+            d = E.f32_to_bf16(rt, d).view(*shp)        # [n, h*w*c] -> bf16 NHWC
+        else:
+            n, c, h, w = shp
+            dn_ = rt.empty(n, c, h, w)
+            L.check(rt.lib.vcg_nhwc_to_nchw(d.data_ptr(), dn_.data_ptr(), n, h, w, c, rt.stream), "vcg_nhwc_to_nchw")
+            d = dn_
         for i, (cv, na) in reversed(list(enumerate(self.convs))):
             d = na.backward(tape.pop(), d, param_grads, which)
             d = cv.backward(tape.pop(), d, need_dx or i > 0, param_grads, which, tag="d_conv")
+            if bf and i == 1:
+                d = E.from_bf16_nhwc(rt, d)
         return d
 
 
 class DiscriminatorPatchGAN(Model):
     """70x70 PatchGAN (north_star extension): C64-C128-C256 (k4 s2),
     C512 (k4 s1), C1 (k4 s1), zero padding 1, LeakyReLU 0.2, instance (default) or batch norm on the
-    three middle blocks."""
+    three middle blocks.  ``dtype='bf16'``: the three middle blocks (99 % of its FLOPs) on bf16 NHWC activations
+    (Conv2DBf16 / NormActBf16); the 3-channel first and the 1-channel last convolution stay fp32."""
     SPEC = ((64, 2, False), (128, 2, True), (256, 2, True), (512, 1, True), (1, 1, False))
 
-    def __init__(self, input_shape, activation, norm, seed):
+    def __init__(self, input_shape, activation, norm, seed, dtype="fp32"):
         super().__init__("discriminator_patchgan_70", input_shape, seed)
+        if dtype not in ("fp32", "bf16"):
+            raise ValueError(dtype)
+        self.dtype = dtype
         self.activation = activation
         self.head = L.HEAD_KINDS.get(activation, L.HEAD_NONE)
         self.convs = []
@@ -597,8 +631,9 @@ class DiscriminatorPatchGAN(Model):
             n = "discriminator/block_%d" % (i + 1)
             last = i == len(self.SPEC) - 1
             if has_norm:
-                cv = self._add(E.Conv2D(n + "/Conv2d", cin, f, 4, s, 1))
-                na = self._add(E.NormAct(n + "/BatchNorm", f, norm, L.ACT_LRELU, 0.2))
+                bf = dtype == "bf16"
+                cv = self._add((E.Conv2DBf16 if bf else E.Conv2D)(n + "/Conv2d", cin, f, 4, s, 1))
+                na = self._add((E.NormActBf16 if bf else E.NormAct)(n + "/BatchNorm", f, norm, L.ACT_LRELU, 0.2))
             else:
                 cv = self._add(E.Conv2D(n + "/Conv2d", cin, f, 4, s, 1, L.ACT_NONE if last else L.ACT_LRELU, 0.2))
                 na = None
@@ -613,9 +648,15 @@ class DiscriminatorPatchGAN(Model):
         return (h, w, 1)
 
     def forward(self, x, training, update_moving=True):
+        rt, bf = self.rt, self.dtype == "bf16"
         tape = []
         h = x
-        for cv, na in self.convs:
+        last = len(self.convs) - 1
+        for i, (cv, na) in enumerate(self.convs):
+            if bf and i == 1:
+                h = E.to_bf16_nhwc(rt, h)
+            if bf and i == last:
+                h = E.from_bf16_nhwc(rt, h)
             h, a = cv.forward(h, tag="d_conv"); tape.append(a)
             if na is not None:
                 h, a = na.forward(h, training, update_moving=update_moving); tape.append(a)
@@ -625,14 +666,20 @@ class DiscriminatorPatchGAN(Model):
         return h, tape
 
     def backward(self, tape, dy, need_dx=False, param_grads=True, which=0):
+        rt, bf = self.rt, self.dtype == "bf16"
         tape = list(tape)
         d = dy
         if self.head:
             d = E.head_act_bwd(self.rt, tape.pop(), d, self.head)
+        last = len(self.convs) - 1
         for i, (cv, na) in reversed(list(enumerate(self.convs))):
             if na is not None:
                 d = na.backward(tape.pop(), d, param_grads, which)
             d = cv.backward(tape.pop(), d, need_dx or i > 0, param_grads, which, tag="d_conv")
+            if bf and i == last:
+                d = E.to_bf16_nhwc(rt, d)
+            if bf and i == 1:
+                d = E.from_bf16_nhwc(rt, d)
         return d
 
 
@@ -648,20 +695,20 @@ def make_upscaler_orig(output_image_shape, kernel_size=5, filters=64, upscale_fa
     return UpscalerOrig(tuple(output_image_shape), kernel_size, filters, upscale_factor, res_block_num, norm, seed, trunk_dtype)
 
 
-def make_discriminator_simple_512(input_shape, activation="none", seed=11):
-    """model.py:836-896"""
+def make_discriminator_simple_512(input_shape, activation="none", seed=11, dtype="fp32"):
+    """model.py:836-896.  ``seed`` / ``dtype`` are extensions: dtype='bf16' keeps the activations of blocks 2..9 in bf16."""
     return DiscriminatorStack(tuple(input_shape), (64, 128, 256, 512, 512, 512, 512, 512, 512), activation, seed,
-                              "discriminator_simple_512")
+                              "discriminator_simple_512", dtype)
 
 
-def make_discriminator_thin_512(input_shape, activation="none", seed=11):
+def make_discriminator_thin_512(input_shape, activation="none", seed=11, dtype="fp32"):
     """model.py:901-961"""
-    return DiscriminatorStack(tuple(input_shape), (64,) + (128,) * 8, activation, seed, "discriminator_thin_512")
+    return DiscriminatorStack(tuple(input_shape), (64,) + (128,) * 8, activation, seed, "discriminator_thin_512", dtype)
 
 
-def make_discriminator_patchgan_70(input_shape, activation="none", norm="instance", seed=11):
+def make_discriminator_patchgan_70(input_shape, activation="none", norm="instance", seed=11, dtype="fp32"):
     """north_star extension following the reference's factory naming pattern."""
-    return DiscriminatorPatchGAN(tuple(input_shape), activation, norm, seed)
+    return DiscriminatorPatchGAN(tuple(input_shape), activation, norm, seed, dtype)
 
 
 # =================================================================================================
