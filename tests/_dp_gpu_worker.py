@@ -11,16 +11,21 @@ sys.path.insert(0, os.path.join(ROOT, "video-cycle_gan-upscaling_amd"))
 
 
 def main():
-    out, mode = sys.argv[1], sys.argv[2]          # mode: eager | graph
+    out, mode = sys.argv[1], sys.argv[2]          # mode: eager | graph | eager-bf16 | graph-bf16 | graph-rel
+    bf16 = mode.endswith("-bf16")
+    rel = mode.endswith("-rel")
+    mode = mode.split("-")[0]
     from upscaler import _dist
     from upscaler import _engine as E
     from upscaler import model as PM
     world = int(os.environ.get("WORLD_SIZE", "1"))
     torch.cuda.set_device(0)
     group = _dist.init_from_env("gloo")
-    G = PM.make_upscaler_orig((64, 64, 3), kernel_size=3, upscale_factor=2, res_block_num=2, norm="instance", seed=7)
-    D = PM.make_discriminator_patchgan_70((64, 64, 3), seed=11)
-    _, _, gan_train = PM.make_and_compile_gan2(G, D, (32, 32, 3), (64, 64, 3), "mse", 1.0, lambda: PM.WassersteinLosses(),
+    G = PM.make_upscaler_orig((64, 64, 3), kernel_size=3, upscale_factor=2, res_block_num=2, norm="instance", seed=7,
+                              trunk_dtype="bf16+tail" if bf16 else "fp32")
+    D = PM.make_discriminator_patchgan_70((64, 64, 3), seed=11, dtype="bf16" if bf16 else "fp32")
+    fac = (lambda: PM.RelativisticLosses(loss_activation="log-sigm")) if rel else (lambda: PM.WassersteinLosses())
+    _, _, gan_train = PM.make_and_compile_gan2(G, D, (32, 32, 3), (64, 64, 3), "mse", 1.0, fac,
                                                1e-2, optimizer=PM.Adam(), process_group=group)
     tr = gan_train.trainer
     tr.g_slots.v.fill_(1.0)          # well-conditioned Adam (see tests/test_model_gpu.py)

@@ -31,15 +31,28 @@ def _run(world, mode, out):
         env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(r), LOCAL_RANK=str(r),
                    WORLD_SIZE=str(world), HSA_ENABLE_IPC_MODE_LEGACY="0")
         procs.append(subprocess.Popen([sys.executable, WORKER, out, mode], env=env))
-    for p in procs:
-        assert p.wait(timeout=600) == 0
+    # collect every rank's exit code; on any failure kill the others (a rank left blocked in a gloo collective would hold
+    # the GPU until the process-group timeout)
+    codes = []
+    try:
+        for p in procs:
+            codes.append(p.wait(timeout=600))
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+                p.wait()
+    assert codes == [0] * world, codes
     return dict(np.load(out))
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["eager", "graph"])
+@pytest.mark.parametrize("mode", ["eager", "graph", "graph-bf16", "graph-rel"])
 def test_two_rank_step_equals_whole_batch_step(tmp_path, mode):
-    one = _run(1, "eager", str(tmp_path / "one.npz"))
+    """fp32 eager / recorded; the all-bf16 models (config C3's arithmetic); the relativistic losses, whose non-linearity needs
+    the GLOBAL means (a 2-float all-reduce inside the step: five graphs per step)"""
+    ref_mode = "eager" + ("-" + mode.split("-")[1] if "-" in mode else "")
+    one = _run(1, ref_mode, str(tmp_path / "one.npz"))
     two = _run(2, mode, str(tmp_path / "two.npz"))
     worst = 0.0
     names = [k for k in one if k != "losses" and not k.startswith("init/")]
