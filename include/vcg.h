@@ -164,6 +164,12 @@ int vcg_head_act_bwd(const float* z, const float* dy, float* dz, size_t count, i
  * after the step). */
 int vcg_gan_loss(const float* mean_a, const float* mean_b, float mean_scale, int kind, float* loss_out, float* da, size_t na,
                  float ga, float* db, size_t nb, float gb, vcg_stream_t stream);
+/* Attention gates of make_upscaler_attention (upscaling/upscaler/model.py:34-36, 86-89): Activation('sigmoid') + Multiply.
+ * fwd: y = sigmoid(a) * m;  bwd: da = dy * m * sigmoid'(a) (gradient wrt the PRE-sigmoid tensor), dm = dy * sigmoid(a) */
+int vcg_sigmoid_gate_fwd(const float* a, const float* m, float* y, size_t count, vcg_stream_t stream);
+int vcg_sigmoid_gate_bwd(const float* a, const float* m, const float* dy, float* da, float* dm, size_t count, vcg_stream_t stream);
+/* Lambda(atanh(0.99999 * x)) applied to the network input (model.py:94): y = atanh(scale * x); no gradient (x is data) */
+int vcg_atanh_scale(const float* x, float* y, size_t count, float scale, vcg_stream_t stream);
 /* y = value everywhere (broadcast gradient of a mean) */
 int vcg_fill(float* y, size_t count, float value, vcg_stream_t stream);
 /* y = a*x + b*y */

@@ -160,6 +160,95 @@ def upscaler_orig_forward(w, x_nhwc, training, res_block_num, upscale_factor, ta
 
 
 # ----------------------------------------------------------------------------------------------
+# generator: make_upscaler_attention (model.py:299-328; blocks :30-48, :78-98) -- train_gan3.py's default ('resnet-att', :55)
+# ----------------------------------------------------------------------------------------------
+def init_upscaler_attention(output_image_shape, kernel_size=5, filters=64, upscale_factor=4, res_block_num=16, seed=7):
+    rng = np.random.RandomState(seed)
+    k, c = kernel_size, output_image_shape[2]
+    w = OrderedDict()
+    _conv_w(w, rng, "initial/conv", 9, 9, c, filters)
+    _prelu_w(w, "initial/prelu", filters)
+    for i in range(res_block_num):
+        n = "res_block/%d" % i
+        _conv_w(w, rng, n + "/attention", k, k, c, filters)
+        _conv_w(w, rng, n + "/conv_pre", k, k, filters, filters)
+        _bn_w(w, n + "/batch_norm_pre", filters)
+        _prelu_w(w, n + "/prelu", filters)
+        _conv_w(w, rng, n + "/conv_post", k, k, filters, filters)
+        _bn_w(w, n + "/batch_norm_post", filters)
+    _conv_w(w, rng, "after_res/conv", k, k, filters, filters)
+    _bn_w(w, "after_res/batch_norm", filters)
+    cin = filters
+    for i in range(int(math.log(upscale_factor, 2))):
+        n, scale = "upscaling/%d/block" % i, 2 ** (i + 1)
+        _conv_w(w, rng, n + "/attention", k, k, 2 * c, cin)                                  # on [nearest, bilinear] of the input
+        _convt_w(w, rng, n + "/conv_transp", k, k, cin, 128)
+        _convt_w(w, rng, n + "/to_add_input_conv_transp", scale + 1, scale + 1, c, 128)
+        cin = 128
+    _conv_w(w, rng, "final/conv", 9, 9, cin, 3)
+    return w
+
+
+def resize_images_tf1(x, factor, interpolation):
+    """K.resize_images(x, f, f, 'channels_last', interpolation) of Keras 2.2.x on TF 1.14: tf.image.resize_nearest_neighbor /
+    resize_bilinear with align_corners=False and NO half-pixel centres (source coordinate = destination * in/out)."""
+    if factor == 1:
+        return x
+    n, c, h, w = x.shape
+    oy = torch.arange(h * factor, dtype=x.dtype) / factor
+    ox = torch.arange(w * factor, dtype=x.dtype) / factor
+    if interpolation == "nearest":
+        return x[:, :, oy.floor().long()][:, :, :, ox.floor().long()]
+    y0, x0 = oy.floor().long(), ox.floor().long()
+    y1, x1 = torch.clamp(y0 + 1, max=h - 1), torch.clamp(x0 + 1, max=w - 1)
+    fy, fx = (oy - y0).view(1, 1, -1, 1), (ox - x0).view(1, 1, 1, -1)
+    top = x[:, :, y0][:, :, :, x0] * (1 - fx) + x[:, :, y0][:, :, :, x1] * fx
+    bot = x[:, :, y1][:, :, :, x0] * (1 - fx) + x[:, :, y1][:, :, :, x1] * fx
+    return top * (1 - fy) + bot * fy
+
+
+def upscaler_attention_forward(w, x_nhwc, training, res_block_num, upscale_factor, taps=None):
+    """[N,h,w,3] -> ([N,h*f,w*f,3], bn_updates)"""
+    upd = OrderedDict()
+
+    def bn(x, name):
+        y, mm, mv = K.batchnorm(x, w[name + "/gamma"], w[name + "/beta"], w[name + "/moving_mean"], w[name + "/moving_variance"], training)
+        if training:
+            upd[name + "/moving_mean"], upd[name + "/moving_variance"] = mm, mv
+        return y
+
+    def conv(x, name, stride=1):
+        return K.conv2d(x, w[name + "/kernel"], w[name + "/bias"], stride, "same")
+
+    def tap(name, t):
+        if taps is not None:
+            taps[name] = t
+        return t
+
+    x = x_nhwc.permute(0, 3, 1, 2)
+    m = K.prelu(conv(x, "initial/conv"), w["initial/prelu/alpha"])
+    skip = m
+    for i in range(res_block_num):
+        n = "res_block/%d" % i
+        gen = m
+        m = torch.sigmoid(conv(x, n + "/attention")) * m                                      # model.py:34-36
+        m = K.prelu(bn(conv(m, n + "/conv_pre"), n + "/batch_norm_pre"), w[n + "/prelu/alpha"])
+        m = bn(conv(m, n + "/conv_post"), n + "/batch_norm_post")
+        m = tap(n + "/final_add", gen + m)
+    m = tap("after_res/add", skip + bn(conv(m, "after_res/conv"), "after_res/batch_norm"))
+    for i in range(int(math.log(upscale_factor, 2))):
+        n, scale = "upscaling/%d/block" % i, 2 ** (i + 1)
+        up = torch.cat([resize_images_tf1(x, scale // 2, "nearest"), resize_images_tf1(x, scale // 2, "bilinear")], 1)   # :80-82
+        m = torch.sigmoid(conv(up, n + "/attention")) * m                                                                  # :86-89
+        m = K.leaky_relu(K.conv2d_transpose_same(m, w[n + "/conv_transp/kernel"], w[n + "/conv_transp/bias"], 2), 0.2)
+        t = torch.atanh(0.99999 * x)                                                                                       # :94
+        t = K.conv2d_transpose_same(t, w[n + "/to_add_input_conv_transp/kernel"], w[n + "/to_add_input_conv_transp/bias"], scale)
+        m = tap(n + "/add_input", m + t)
+    m = torch.tanh(conv(m, "final/conv"))
+    return m.permute(0, 2, 3, 1), upd
+
+
+# ----------------------------------------------------------------------------------------------
 # discriminators
 # ----------------------------------------------------------------------------------------------
 _SIMPLE_FILTERS = (64, 128, 256, 512, 512, 512, 512, 512, 512)     # model.py:839-871

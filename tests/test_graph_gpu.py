@@ -94,3 +94,85 @@ def test_custom_generator_with_downsampling_block_matches_oracle(rt):
     worst = max(float((net.ps.grad(k).cpu().double() - grads[k]).abs().max() / (grads[k].abs().max() + 1e-3 * gmax)) for k in names)
     report("custom generator (downsampling_block) fwd err=%.2e worst grad err=%.2e" % (e_f, worst))
     assert e_f < 1e-3 and worst < 5e-3
+
+
+def test_upscaler_attention_matches_oracle(rt):
+    """make_upscaler_attention (model.py:299-328), train_gan3.py's default generator, at upscale_factor=2: parameter count,
+    inference and training-mode forward, every parameter gradient against the fp64 oracle (autograd)."""
+    from oracle import models as M
+    from upscaler import _engine as E, model as PM
+    out_shape, res, k = (64, 96, 3), 3, 3
+    gw = M.init_upscaler_attention(out_shape, k, 64, 2, res, seed=5)
+    rng = np.random.RandomState(2)
+    for n_, v in gw.items():                              # non-trivial BN / PReLU parameters
+        if n_.endswith(("/bias", "/beta", "/moving_mean")):
+            gw[n_] = rng.uniform(-0.1, 0.1, v.shape).astype(np.float32)
+        elif n_.endswith(("/gamma", "/moving_variance")):
+            gw[n_] = rng.uniform(0.8, 1.2, v.shape).astype(np.float32)
+        elif n_.endswith("/alpha"):
+            gw[n_] = rng.uniform(0.0, 0.3, v.shape).astype(np.float32)
+    G = PM.make_upscaler_attention(out_shape, kernel_size=k, upscale_factor=2, res_block_num=res)
+    assert G.count_params() == M.count_params(gw)
+    assert G.input_shape == (None, 32, 48, 3) and G.output_shape == (None, 64, 96, 3)
+    G.set_weights_dict(gw)
+    x = (rng.randint(0, 256, (2, 32, 48, 3)) / 127.5 - 1).astype(np.float32)
+    t = (rng.randint(0, 256, (2, 64, 96, 3)) / 127.5 - 1).astype(np.float32)
+    with torch.no_grad():
+        y0, _ = M.upscaler_attention_forward(M.to_torch(gw, torch.float64), torch.tensor(x, dtype=torch.float64), False, res, 2)
+    e0 = rel_err(torch.tensor(G.predict(x)), y0)
+    leaf = M.to_torch(gw, torch.float64, requires_grad=True)
+    y, upd = M.upscaler_attention_forward(leaf, torch.tensor(x, dtype=torch.float64), True, res, 2)
+    loss = ((y - torch.tensor(t, dtype=torch.float64)) ** 2).mean()
+    names = [n_ for n_, v in leaf.items() if v.requires_grad]
+    grads = dict(zip(names, torch.autograd.grad(loss, [leaf[n_] for n_ in names])))
+    leaf32 = M.to_torch(gw, torch.float32, requires_grad=True)
+    y32, _ = M.upscaler_attention_forward(leaf32, torch.tensor(x), True, res, 2)
+    g32 = dict(zip(names, torch.autograd.grad(((y32 - torch.tensor(t)) ** 2).mean(), [leaf32[n_] for n_ in names])))
+    yd, tape = G.forward(E.to_device_nchw(rt, x), True)
+    e1 = rel_err(E.to_nhwc(rt, yd), y)
+    val, dy = PM._pixel_loss(rt, yd, E.to_device_nchw(rt, t), "mse", 1.0)
+    G.backward(tape, dy, 0)
+    gmax = max(float(g.abs().max()) for g in grads.values())
+    worst = 0.0
+    for n_ in names:
+        a, b = G.ps.grad(n_).cpu().double(), grads[n_]
+        err = float((a - b).abs().max() / (b.abs().max() + 1e-4 * gmax))
+        e32 = float((g32[n_].double() - b).abs().max() / (b.abs().max() + 1e-4 * gmax))
+        worst = max(worst, err)
+        assert err < max(1e-3, 4 * e32), (n_, err, e32)
+    sw = G.get_weights_dict()
+    for n_, v in upd.items():
+        assert np.max(np.abs(sw[n_] - v.detach().numpy())) < 1e-4 * (np.max(np.abs(v.detach().numpy())) + 1e-3), n_
+    report("make_upscaler_attention: predict err=%.2e train fwd err=%.2e worst gradient err=%.2e" % (e0, e1, worst))
+    assert e0 < 1e-3 and e1 < 1e-3
+
+
+def test_train_gan3_default_model_choice_trains(rt):
+    """train_gan3.py's default model and loss selection (:55-63: -gm resnet-att, -dm s512, -da bi-log, -dl rel, -dla log-sigm)
+    through make_and_compile_gan2 and two loop-body iterations, against the fp64 oracle (x2, pixel-MSE content loss)."""
+    from oracle import models as M, train as T
+    from upscaler import model as PM, _lib as L
+    res, k, bs = 2, 3, 4
+    gw = M.init_upscaler_attention((128, 128, 3), k, 64, 2, res, seed=7)
+    dw = M.init_discriminator_512((128, 128, 3), "simple", seed=11)
+    G = PM.make_upscaler_attention((128, 128, 3), kernel_size=k, upscale_factor=2, res_block_num=res)
+    D = PM.make_discriminator_simple_512((128, 128, 3), activation="bi-log")
+    G.set_weights_dict(gw)
+    D.set_weights_dict(dw)
+    gen_train, disc_train, gan_train = PM.make_and_compile_gan2(
+        G, D, (64, 64, 3), (128, 128, 3), "mse", 1, lambda: PM.RelativisticLosses(loss_activation="log-sigm"), 1e-2, optimizer=PM.Adam())
+    tr = gan_train.trainer
+    for s in (tr.g_slots, tr.d_slots):
+        L.check(rt.lib.vcg_fill(s.v.data_ptr(), s.v.numel(), 1.0, rt.stream), "vcg_fill")
+    orc = T.GanOracle(lambda w, x, t: M.upscaler_attention_forward(w, x, t, res, 2), M.to_torch(gw, torch.float64),
+                      lambda w, x, t: M.discriminator_512_forward(w, x, t, activation="bi-log"), M.to_torch(dw, torch.float64),
+                      losses="rel", loss_activation="log-sigm", discriminator_loss_weight=1e-2, adam_v0=1.0)
+    for it in range(2):
+        lr, hr = _frames(50 + it, bs, 64, 64), _frames(60 + it, bs, 128, 128)
+        fake = gen_train.predict(lr)
+        got = (disc_train.train_on_batch([hr, fake], -np.ones(bs)),) + tuple(gan_train.train_on_batch([lr, hr], [hr, -np.ones(bs)]))
+        ref = orc.train_step(torch.tensor(lr, dtype=torch.float64), torch.tensor(hr, dtype=torch.float64))
+        scale = max(abs(v) for v in ref)
+        report("train_gan3 default models it=%d got=%s ref=%s" % (it, ["%.6g" % v for v in got], ["%.6g" % v for v in ref]))
+        for a, b in zip(got, ref):
+            assert abs(a - b) < 1e-3 * scale, (got, ref)

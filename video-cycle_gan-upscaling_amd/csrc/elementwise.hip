@@ -343,6 +343,28 @@ __global__ void gan_loss_kernel(const float* mean_a, const float* mean_b, float 
     for (size_t k = i; k < nb; k += stride) db[k] = (float)(g * (double)gb);
 }
 
+// ---- attention gates of make_upscaler_attention (model.py:34-36, 86-89): y = sigmoid(a) * m -------------------------------
+__global__ void sigmoid_gate_fwd_kernel(const float* a, const float* m, float* y, size_t count) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < count) y[i] = m[i] / (1.f + expf(-a[i]));
+}
+
+// da = dy * m * s(1-s)  (the gradient in front of the sigmoid), dm = dy * s
+__global__ void sigmoid_gate_bwd_kernel(const float* a, const float* m, const float* dy, float* da, float* dm, size_t count) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= count) return;
+    const float av = a[i], d = dy[i];
+    const float s = 1.f / (1.f + expf(-av)), sd = 1.f / ((1.f + expf(-av)) * (1.f + expf(av)));
+    da[i] = d * m[i] * sd;
+    dm[i] = d * s;
+}
+
+// Lambda(lambda x: tf.math.atanh(0.99999 * x)) on the network input (model.py:94): y = atanh(scale * x), evaluated in double
+__global__ void atanh_scale_kernel(const float* x, float* y, size_t count, float scale) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < count) y[i] = (float)atanh((double)scale * (double)x[i]);
+}
+
 inline unsigned blocks_for(size_t count) { return (unsigned)((count + 255) / 256); }
 
 }  // namespace
@@ -468,6 +490,30 @@ int vcg_gan_loss(const float* mean_a, const float* mean_b, float mean_scale, int
     if (nbk > 1024) nbk = 1024;
     hipLaunchKernelGGL(gan_loss_kernel, dim3(nbk), dim3(256), 0, (hipStream_t)stream, mean_a, mean_b, mean_scale, kind, loss_out,
                        da, na, ga, db, nb, gb);
+    VCG_LAUNCH_CHECK();
+    return VCG_OK;
+}
+
+int vcg_sigmoid_gate_fwd(const float* a, const float* m, float* y, size_t count, vcg_stream_t stream) {
+    VCG_CHECK_PTR(a); VCG_CHECK_PTR(m); VCG_CHECK_PTR(y);
+    if (count == 0) return VCG_OK;
+    hipLaunchKernelGGL(sigmoid_gate_fwd_kernel, dim3(blocks_for(count)), dim3(256), 0, (hipStream_t)stream, a, m, y, count);
+    VCG_LAUNCH_CHECK();
+    return VCG_OK;
+}
+
+int vcg_sigmoid_gate_bwd(const float* a, const float* m, const float* dy, float* da, float* dm, size_t count, vcg_stream_t stream) {
+    VCG_CHECK_PTR(a); VCG_CHECK_PTR(m); VCG_CHECK_PTR(dy); VCG_CHECK_PTR(da); VCG_CHECK_PTR(dm);
+    if (count == 0) return VCG_OK;
+    hipLaunchKernelGGL(sigmoid_gate_bwd_kernel, dim3(blocks_for(count)), dim3(256), 0, (hipStream_t)stream, a, m, dy, da, dm, count);
+    VCG_LAUNCH_CHECK();
+    return VCG_OK;
+}
+
+int vcg_atanh_scale(const float* x, float* y, size_t count, float scale, vcg_stream_t stream) {
+    VCG_CHECK_PTR(x); VCG_CHECK_PTR(y);
+    if (count == 0) return VCG_OK;
+    hipLaunchKernelGGL(atanh_scale_kernel, dim3(blocks_for(count)), dim3(256), 0, (hipStream_t)stream, x, y, count, scale);
     VCG_LAUNCH_CHECK();
     return VCG_OK;
 }

@@ -75,6 +75,9 @@ SIGNATURES = {
     "vcg_axpby": (c_int, [_P, _P, c_size_t, c_float, c_float, _P]),
     "vcg_adam_keras_multi": (c_int, [_P, _P, _P, _P, c_size_t, c_float, c_float, c_float, c_float, c_float, _P]),
     "vcg_adam_keras_multi_dev": (c_int, [_P, _P, _P, _P, c_size_t, c_float, c_float, c_float, c_float, c_float, _P, _P]),
+    "vcg_sigmoid_gate_fwd": (c_int, [_P, _P, _P, c_size_t, _P]),
+    "vcg_sigmoid_gate_bwd": (c_int, [_P, _P, _P, _P, _P, c_size_t, _P]),
+    "vcg_atanh_scale": (c_int, [_P, _P, c_size_t, c_float, _P]),
     "vcg_head_act_fwd": (c_int, [_P, _P, c_size_t, c_int, _P]),
     "vcg_head_act_bwd": (c_int, [_P, _P, _P, c_size_t, c_int, _P]),
     "vcg_gan_loss": (c_int, [_P, _P, c_float, c_int, _P, _P, c_size_t, c_float, _P, c_size_t, c_float, _P]),

@@ -1194,5 +1194,6 @@ def compile_training_model(upscaler, loss, optimizer=_DEFAULT_ADAM):
 # =================================================================================================
 # functional block API (model.py:15-27, 63-75) -- see _graph.py
 # =================================================================================================
-from ._graph import (Input, add, batch_norm, build_model, conv2d, downsampling_block, leaky_relu,  # noqa: E402,F401
-                     make_upscaler_orig_functional, prelu, residual_block, upsampling_block)
+from ._graph import (Input, add, atanh_scaled, batch_norm, build_model, concatenate, conv2d, conv2d_transpose,  # noqa: E402,F401
+                     downsampling_block, leaky_relu, make_upscaler_attention, make_upscaler_orig_functional, multiply_sigmoid,
+                     prelu, residual_block, residual_block_attention, resize_images, upsampling_block, upsampling_block_attention)
