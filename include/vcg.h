@@ -170,6 +170,10 @@ int vcg_sigmoid_gate_fwd(const float* a, const float* m, float* y, size_t count,
 int vcg_sigmoid_gate_bwd(const float* a, const float* m, const float* dy, float* da, float* dm, size_t count, vcg_stream_t stream);
 /* Lambda(atanh(0.99999 * x)) applied to the network input (model.py:94): y = atanh(scale * x); no gradient (x is data) */
 int vcg_atanh_scale(const float* x, float* y, size_t count, float scale, vcg_stream_t stream);
+/* zero insertion dst[plane][y*s][x*s] = src[plane][y][x] (dst: (h-1)*s+1 x (w-1)*s+1, zeros elsewhere).  The data gradient of a
+ * stride-3 convolution (make_discriminator_sparse_512, upscaling/upscaler/model.py:971-987) = vcg_conv2d_dgrad with stride 1 over
+ * the dilated gradient. */
+int vcg_dilate2d(const float* src, float* dst, size_t planes, int h, int w, int stride, vcg_stream_t stream);
 /* y = value everywhere (broadcast gradient of a mean) */
 int vcg_fill(float* y, size_t count, float value, vcg_stream_t stream);
 /* y = a*x + b*y */

@@ -317,6 +317,50 @@ def discriminator_512_forward(w, x_nhwc, training, activation="none", taps=None,
     return K.head_activation(m, activation), upd
 
 
+_SPARSE_FILTERS = (64, 128, 256, 256, 256, 256)                       # model.py:967-987: 5x5 'valid', strides 1,3,3,3,3,3
+
+
+def init_discriminator_sparse_512(input_shape, seed=11):
+    """make_discriminator_sparse_512 (model.py:964-1012)"""
+    rng = np.random.RandomState(seed)
+    w = OrderedDict()
+    cin, h, ww = input_shape[2], input_shape[0], input_shape[1]
+    for i, f in enumerate(_SPARSE_FILTERS):
+        n = "discriminator/block_%d" % (i + 1)
+        _conv_w(w, rng, n + "/Conv2d", 5, 5, cin, f)
+        _bn_w(w, n + "/BatchNorm", f)
+        s = 1 if i == 0 else 3
+        h, ww = (h - 5) // s + 1, (ww - 5) // s + 1
+        cin = f
+    _dense_w(w, rng, "discriminator/final/Dense_1", h * ww * cin, 128)
+    _bn_w(w, "discriminator/final/BatchNorm_1", 128)
+    _dense_w(w, rng, "discriminator/final/Dense_2", 128, 32)
+    _bn_w(w, "discriminator/final/BatchNorm_2", 32)
+    _dense_w(w, rng, "discriminator/final/Dense_3", 32, 1)
+    return w
+
+
+def discriminator_sparse_512_forward(w, x_nhwc, training, activation="none"):
+    upd = OrderedDict()
+
+    def bn(x, name):
+        y, mm, mv = K.batchnorm(x, w[name + "/gamma"], w[name + "/beta"], w[name + "/moving_mean"], w[name + "/moving_variance"], training)
+        if training:
+            upd[name + "/moving_mean"], upd[name + "/moving_variance"] = mm, mv
+        return y
+    m = x_nhwc.permute(0, 3, 1, 2)
+    for i in range(len(_SPARSE_FILTERS)):
+        n = "discriminator/block_%d" % (i + 1)
+        m = K.conv2d(m, w[n + "/Conv2d/kernel"], w[n + "/Conv2d/bias"], 1 if i == 0 else 3, "valid")
+        m = K.leaky_relu(bn(m, n + "/BatchNorm"), 0.1)
+    m = K.flatten_nhwc(m)
+    for j in (1, 2):
+        m = K.dense(m, w["discriminator/final/Dense_%d/kernel" % j], w["discriminator/final/Dense_%d/bias" % j])
+        m = K.leaky_relu(bn(m, "discriminator/final/BatchNorm_%d" % j), 0.1)
+    m = K.dense(m, w["discriminator/final/Dense_3/kernel"], w["discriminator/final/Dense_3/bias"])
+    return K.head_activation(m, activation), upd
+
+
 _PATCH_SPEC = ((64, 2, None), (128, 2, "norm"), (256, 2, "norm"), (512, 1, "norm"), (1, 1, "last"))
 
 

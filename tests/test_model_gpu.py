@@ -536,3 +536,48 @@ def test_reference_default_generator_x4_16blocks_k5(rt):
     report("reference-default generator (k5, x4, 16 blocks) predict err=%.2e train fwd err=%.2e worst gradient err=%.2e" % (e0, e1, worst))
     assert e0 < TOL and e1 < TOL
     assert abs(val.item() - loss.item()) / loss.item() < 1e-4
+
+
+def test_discriminator_sparse_512(rt):
+    """make_discriminator_sparse_512 (model.py:964-1012): 5x5 'valid' convolutions of stride 1 and 3 at the 512x512 frames it is
+    written for: parameter count (model.py:964-1012 layer by layer), inference output, training-mode output, input gradient and every parameter
+    gradient against the fp64 oracle."""
+    from oracle import models as M
+    from upscaler import _engine as E, model as PM
+    dw = _perturb(M.init_discriminator_sparse_512((512, 512, 3), seed=11), 4)
+    D = PM.make_discriminator_sparse_512((512, 512, 3), "tanh")
+    assert D.count_params() == M.count_params(dw) == 5987777
+    D.set_weights_dict(dw)
+    n = 3
+    x = _frames(6, n, 512, 512)
+    with torch.no_grad():
+        y0, _ = M.discriminator_sparse_512_forward(M.to_torch(dw, torch.float64), torch.tensor(x, dtype=torch.float64), False, "tanh")
+    e0 = rel_err(torch.tensor(D.predict(x)), y0)
+    def oracle(dt):
+        leaf = M.to_torch(dw, dt, requires_grad=True)
+        xi = torch.tensor(x, dtype=dt, requires_grad=True)
+        y, _ = M.discriminator_sparse_512_forward(leaf, xi, True, "tanh")
+        coef = torch.tensor([[1.0], [-0.5], [0.25]], dtype=dt)
+        names = [k for k, v in leaf.items() if v.requires_grad]
+        gs = torch.autograd.grad((y * coef).sum(), [leaf[k] for k in names] + [xi])
+        return y.detach().double(), names, [g.double() for g in gs]
+    y, names, gs = oracle(torch.float64)
+    _, _, gs32 = oracle(torch.float32)
+    yd, tape = D.forward(E.to_device_nchw(rt, x), True, True)
+    e1 = rel_err(yd, y)
+    dx = D.backward(tape, torch.tensor([[1.0], [-0.5], [0.25]], device=rt.device), True, True, 0)
+    gmax = max(float(g.abs().max()) for g in gs[:-1])
+    worst, bad = 0.0, []
+    got = [D.ps.grad(k).cpu().double() for k in names] + [E.to_nhwc(rt, dx).cpu().double()]
+    for k, a, b, b32 in zip(names + ["input"], got, gs, gs32):
+        fl = 1e-4 * (gmax if k != "input" else float(b.abs().max()))
+        e = float((a - b).abs().max() / (b.abs().max() + fl))
+        e32 = float((b32 - b).abs().max() / (b.abs().max() + fl))
+        worst = max(worst, e)
+        # BatchNormalization over 3 samples of 1x1 maps (block 6 and the Dense head) makes these gradients ill-conditioned in ANY
+        # fp32 run: the oracle's own fp32 evaluation sits 1e-2 .. 4e-2 from its fp64 one; bound = 4x that, floor 2e-3
+        if not e < max(2e-3, 4 * e32):
+            bad.append((k, e, e32))
+    report("sparse_512: predict err=%.2e train fwd err=%.2e worst gradient err=%.2e" % (e0, e1, worst))
+    assert not bad, bad
+    assert e0 < TOL and e1 < TOL

@@ -122,3 +122,22 @@ def test_vgg19_notop_param_count_and_shapes():
     assert len(w) == 32 and w["block1_conv1/kernel"].shape == (3, 3, 3, 64) and w["block5_conv4/kernel"].shape == (3, 3, 512, 512)
     f = M.vgg19_block5_conv4(M.to_torch(w), torch.zeros(1, 32, 48, 3))
     assert tuple(f.shape) == (1, 2, 3, 512) and float(f.min()) >= 0.0
+
+
+def test_sparse_512_and_attention_generator_sizes():
+    """make_discriminator_sparse_512 at 512x512 has 5 987 777 parameters, counted layer by layer from model.py:964-1012 (SURVEY.md
+    Appendix B says 5 987 137: it leaves out the 4 x (128 + 32) parameters of the Dense head's two BatchNormalizations, :999,:1003; spatial 512 -> 508 -> 168 -> 55 ->
+    17 -> 5 -> 1); the attention generator's parameter count follows from model.py:30-48,78-98,299-328."""
+    from oracle import models as M
+    w = M.init_discriminator_sparse_512((512, 512, 3))
+    assert M.count_params(w) == 5987777
+    assert w["discriminator/final/Dense_1/kernel"].shape == (256, 128)
+    y, _ = M.discriminator_sparse_512_forward(M.to_torch(w), torch.zeros(1, 512, 512, 3), False)
+    assert tuple(y.shape) == (1, 1)
+    k, f, res, c = 3, 64, 2, 3
+    gw = M.init_upscaler_attention((64, 64, 3), k, f, 2, res)
+    conv = lambda kk, ci, co: kk * kk * ci * co + co
+    bn = 4 * f
+    expect = conv(9, c, f) + f + res * (conv(k, c, f) + 2 * conv(k, f, f) + 2 * bn + f) + conv(k, f, f) + bn \
+        + conv(k, 2 * c, f) + conv(k, f, 128) + conv(3, c, 128) + conv(9, 128, 3)
+    assert M.count_params(gw) == expect

@@ -19,7 +19,7 @@ int check_desc(const vcg_conv_desc* d) {
     if (d == nullptr) return VCG_E_NULL;
     if (d->n <= 0 || d->cin <= 0 || d->h <= 0 || d->w <= 0 || d->cout <= 0 || d->oh <= 0 || d->ow <= 0)
         return VCG_E_SHAPE;
-    if (d->kh <= 0 || d->kw <= 0 || (d->stride != 1 && d->stride != 2)) return VCG_E_UNSUPPORTED;
+    if (d->kh <= 0 || d->kw <= 0 || d->stride < 1 || d->stride > 3) return VCG_E_UNSUPPORTED;
     if (d->pad_top < 0 || d->pad_left < 0 || d->pad_top >= d->kh || d->pad_left >= d->kw) return VCG_E_SHAPE;
     return VCG_OK;
 }
@@ -84,7 +84,8 @@ int vcg_conv2d_dgrad(const vcg_conv_desc* d, const float* dy, const float* w_hwi
                                  pl, 1, &ep, 0, 0, 0, 0, st);
     }
     // stride 2: dx[ci][i] = sum_{co,j,k: 2j+k-p=i} dy[co][j] * W[k][ci][co]  == transposed conv, crop p
-    if (d->kh != d->kw) return VCG_E_UNSUPPORTED;
+    // (stride 3 -- sparse_512 only -- is served by the caller: vcg_dilate2d of dy, then this function with stride 1)
+    if (d->kh != d->kw || d->stride != 2) return VCG_E_UNSUPPORTED;
     VCG_CHECK_PTR(w_hwoi);
     return vcg_internal_convt(dy, w_hwoi, dx, d->n, d->cout, d->oh, d->ow, d->cin, d->h, d->w, d->kh, d->pad_top,
                               d->pad_left, &ep, st);

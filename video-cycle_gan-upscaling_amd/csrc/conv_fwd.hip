@@ -571,6 +571,7 @@ int vcg_internal_conv(const float* x, const float* w, float* y, int n, int cin, 
         if (kh == 9 && kw == 9 && stride == 1) return launch_c3<9, 9, 1>(p, st);
         if (kh == 3 && kw == 3 && stride == 1) return launch_c3<3, 3, 1>(p, st);
         if (kh == 4 && kw == 4 && stride == 2) return launch_c3<4, 4, 2>(p, st);
+        if (kh == 5 && kw == 5 && stride == 1) return launch_c3<5, 5, 1>(p, st);     // sparse_512 block 1 (model.py:967)
     }
     // wide outputs use 64-column tiles (two MFMA x-tiles per wave: half the barriers and weight staging per
     // MFMA, and 1024 workgroups = 2 full rounds of 2 per CU at the C2 trunk shape instead of 2.67 rounds of 3)
@@ -581,6 +582,7 @@ int vcg_internal_conv(const float* x, const float* w, float* y, int n, int cin, 
     if (kh == 4 && kw == 4 && stride == 2) return launch_conv<4, 4, 2, 4, 1>(p, st);
     if (kh == 5 && kw == 5 && stride == 1) return launch_conv<5, 5, 1, 8, 1>(p, st);   // XT=2 spills (50 weight prefetch registers)
     if (kh == 5 && kw == 5 && stride == 2) return launch_conv<5, 5, 2, 4, 1>(p, st);
+    if (kh == 5 && kw == 5 && stride == 3) return launch_conv<5, 5, 3, 4, 1>(p, st);   // sparse_512 blocks 2-6 (model.py:971-987)
     if (kh == 9 && kw == 9 && stride == 1) return launch_conv<9, 9, 1, 4, 1>(p, st);
     return VCG_E_UNSUPPORTED;
 }

@@ -300,7 +300,7 @@ inline void pick_layout(int K, int S, int jtot, int* nw, int* nj, int* mw) {
     switch (K) {
         case 3: if (jtot <= 256) { *nw = 4; *nj = 2; } else { *nw = 4; *nj = 9; *mw = 1; } return;   // 18 tiles = 64 channels
         case 4: if (S == 2) { *nw = 4; *nj = 2; } else { *nw = 4; *nj = 8; *mw = 1; } return;        // 8 tiles = 16 ch / 16 tiles = 32 ch
-        case 5: if (jtot <= 256) { *nw = 4; *nj = 2; } else { *nw = 4; *nj = 13; *mw = 1; } return;  // 26 tiles = 33 channels
+        case 5: if (jtot <= 256 || S == 3) { *nw = 4; *nj = 2; } else { *nw = 4; *nj = 13; *mw = 1; } return;  // 26 tiles = 33 channels (stride 3: small layout)
         case 9: *nw = 4; *nj = 2; return;                                                             // 8 tiles = 3 channels
         default: *nw = 0; *nj = 0; return;
     }
@@ -309,7 +309,7 @@ inline void pick_layout(int K, int S, int jtot, int* nw, int* nj, int* mw) {
 Plan make_plan(int n, int mtot, int ah, int aw, int jctot, int kh, int kw, int S) {
     Plan pl{};
     pl.ok = false;
-    if (kh != kw || (S != 1 && S != 2) || (kh == 9 && S != 1)) return pl;
+    if (kh != kw || S < 1 || S > 3 || (S == 3 && kh != 5) || (kh == 9 && S != 1)) return pl;
     const int T = kh * kw;
     pl.S = S; pl.K = kh;
     pl.TH = (S == 1) ? 2 : 1;
@@ -387,6 +387,7 @@ int vcg_internal_wgrad(const float* A, const float* B, float* dw, float* db, int
     VCG_WG(2, 2, 1, 2, 1, 4); VCG_WG(2, 4, 2, 2, 1, 4);
     VCG_WG(1, 4, 2, 2, 2, 5); VCG_WG(1, 4, 13, 1, 2, 5);
     VCG_WG(2, 4, 2, 2, 1, 5); VCG_WG(2, 4, 13, 1, 1, 5);
+    VCG_WG(3, 4, 2, 2, 1, 5);            // sparse_512 (model.py:971-987): 5x5 stride 3
     VCG_WG(1, 4, 2, 2, 2, 9);
 #undef VCG_WG
     if (rc != VCG_OK) return rc;

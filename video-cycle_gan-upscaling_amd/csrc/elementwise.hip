@@ -365,6 +365,18 @@ __global__ void atanh_scale_kernel(const float* x, float* y, size_t count, float
     if (i < count) y[i] = (float)atanh((double)scale * (double)x[i]);
 }
 
+// zero insertion: dst[plane][y*s][x*s] = src[plane][y][x], zeros elsewhere (data gradient of a stride-3 convolution as a
+// stride-1 correlation over the dilated gradient)
+__global__ void dilate2d_kernel(const float* __restrict__ src, float* __restrict__ dst, size_t planes, int h, int w, int s) {
+    const int dh = (h - 1) * s + 1, dw = (w - 1) * s + 1;
+    const size_t total = planes * dh * dw;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int x = (int)(i % dw), y = (int)((i / dw) % dh);
+    const size_t pl = i / ((size_t)dw * dh);
+    dst[i] = (x % s == 0 && y % s == 0) ? src[(pl * h + y / s) * w + x / s] : 0.f;
+}
+
 inline unsigned blocks_for(size_t count) { return (unsigned)((count + 255) / 256); }
 
 }  // namespace
@@ -514,6 +526,15 @@ int vcg_atanh_scale(const float* x, float* y, size_t count, float scale, vcg_str
     VCG_CHECK_PTR(x); VCG_CHECK_PTR(y);
     if (count == 0) return VCG_OK;
     hipLaunchKernelGGL(atanh_scale_kernel, dim3(blocks_for(count)), dim3(256), 0, (hipStream_t)stream, x, y, count, scale);
+    VCG_LAUNCH_CHECK();
+    return VCG_OK;
+}
+
+int vcg_dilate2d(const float* src, float* dst, size_t planes, int h, int w, int stride, vcg_stream_t stream) {
+    VCG_CHECK_PTR(src); VCG_CHECK_PTR(dst);
+    if (planes == 0 || h <= 0 || w <= 0 || stride < 1) return VCG_E_SHAPE;
+    const size_t total = planes * ((size_t)(h - 1) * stride + 1) * ((size_t)(w - 1) * stride + 1);
+    hipLaunchKernelGGL(dilate2d_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, src, dst, planes, h, w, stride);
     VCG_LAUNCH_CHECK();
     return VCG_OK;
 }

@@ -277,8 +277,15 @@ class Conv2D(Layer):
         dx = None
         if need_dx:
             dx = rt.empty(n, self.cin, d.h, d.w)
+            dd, dyd = d, dy
+            if self.stride > 2:
+                # sparse_512's stride-3 layers: the data gradient as a stride-1 correlation over the zero-dilated gradient
+                s = self.stride
+                dyd = rt.empty(n, self.cout, (d.oh - 1) * s + 1, (d.ow - 1) * s + 1)
+                L.check(rt.lib.vcg_dilate2d(dy.data_ptr(), dyd.data_ptr(), n * self.cout, d.oh, d.ow, s, rt.stream), "vcg_dilate2d")
+                dd = L.ConvDesc(n, self.cin, d.h, d.w, self.cout, dyd.shape[2], dyd.shape[3], self.k, self.k, 1, d.pad_top, d.pad_left)
             with Timed(rt, tag and tag + "_dgrad"):
-                L.check(rt.lib.vcg_conv2d_dgrad(ctypes.byref(d), dy.data_ptr(), self.ps[self.name + "/kernel"].data_ptr(),
+                L.check(rt.lib.vcg_conv2d_dgrad(ctypes.byref(dd), dyd.data_ptr(), self.ps[self.name + "/kernel"].data_ptr(),
                                                 self._wt().data_ptr(), dx.data_ptr(), _ptr(dx_residual), rt.stream),
                         "vcg_conv2d_dgrad[%s]" % self.name)
         return dx

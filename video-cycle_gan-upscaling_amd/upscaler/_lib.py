@@ -71,6 +71,7 @@ SIGNATURES = {
     "vcg_mean_reduce_workspace_bytes": (c_size_t, [c_size_t]),
     "vcg_mean_reduce": (c_int, [_P, c_size_t, _P, _P, c_size_t, _P]),
     "vcg_pixel_loss": (c_int, [_P, _P, c_size_t, c_int, c_float, _P, _P, _P, c_size_t, _P]),
+    "vcg_dilate2d": (c_int, [_P, _P, c_size_t, c_int, c_int, c_int, _P]),
     "vcg_fill": (c_int, [_P, c_size_t, c_float, _P]),
     "vcg_axpby": (c_int, [_P, _P, c_size_t, c_float, c_float, _P]),
     "vcg_adam_keras_multi": (c_int, [_P, _P, _P, _P, c_size_t, c_float, c_float, c_float, c_float, c_float, _P]),

@@ -521,10 +521,11 @@ class DiscriminatorStack(Model):
     accumulation, statistics, master weights and gradients); block 1 (3 input channels) and the Dense head stay fp32.  Flatten of
     the NHWC tensor is its memory order, so entering the head is a flat bf16 -> fp32 conversion."""
 
-    def __init__(self, input_shape, filters, activation, seed, name, dtype="fp32"):
+    def __init__(self, input_shape, filters, activation, seed, name, dtype="fp32", kernel=3, strides=None, padding="same", dense1=1024):
         super().__init__(name, input_shape, seed)
         if dtype not in ("fp32", "bf16"):
             raise ValueError(dtype)
+        strides = strides or (1,) + (2,) * (len(filters) - 1)
         self.dtype = dtype
         self.activation = activation
         self.head = L.HEAD_KINDS.get(activation, L.HEAD_NONE)     # any other string: no activation, like the reference's if/elif chain
@@ -533,19 +534,20 @@ class DiscriminatorStack(Model):
         h, w = input_shape[0], input_shape[1]
         for i, f in enumerate(filters):
             n = "discriminator/block_%d" % (i + 1)
-            s = 1 if i == 0 else 2
+            s = strides[i]
             bf = dtype == "bf16" and i > 0
             conv = E.Conv2DBf16 if bf else E.Conv2D
             norm = E.NormActBf16 if bf else E.NormAct
-            self.convs.append((self._add(conv(n + "/Conv2d", cin, f, 3, s)),
-                               self._add(norm(n + "/BatchNorm", f, "batch", L.ACT_LRELU, 0.1))))
-            if s == 2:
-                h, w = -(-h // 2), -(-w // 2)
+            cv = self._add(conv(n + "/Conv2d", cin, f, kernel, s, padding))
+            self.convs.append((cv, self._add(norm(n + "/BatchNorm", f, "batch", L.ACT_LRELU, 0.1))))
+            h, w, _, _ = cv.out_hw(h, w)
+            if h < 1 or w < 1:
+                raise ValueError("input %s is too small for %s" % (tuple(input_shape), name))
             cin = f
         self.flat = (h, w, cin)
-        self.d1 = self._add(E.Dense("discriminator/final/Dense_1", h * w * cin, 1024))
-        self.b1 = self._add(E.NormAct("discriminator/final/BatchNorm_1", 1024, "batch", L.ACT_LRELU, 0.1))
-        self.d2 = self._add(E.Dense("discriminator/final/Dense_2", 1024, 32))
+        self.d1 = self._add(E.Dense("discriminator/final/Dense_1", h * w * cin, dense1))
+        self.b1 = self._add(E.NormAct("discriminator/final/BatchNorm_1", dense1, "batch", L.ACT_LRELU, 0.1))
+        self.d2 = self._add(E.Dense("discriminator/final/Dense_2", dense1, 32))
         self.b2 = self._add(E.NormAct("discriminator/final/BatchNorm_2", 32, "batch", L.ACT_LRELU, 0.1))
         self.d3 = self._add(E.Dense("discriminator/final/Dense_3", 32, 1))
         self._finish()
@@ -704,6 +706,12 @@ def make_discriminator_simple_512(input_shape, activation="none", seed=11, dtype
 def make_discriminator_thin_512(input_shape, activation="none", seed=11, dtype="fp32"):
     """model.py:901-961"""
     return DiscriminatorStack(tuple(input_shape), (64,) + (128,) * 8, activation, seed, "discriminator_thin_512", dtype)
+
+
+def make_discriminator_sparse_512(input_shape, activation="none", seed=11):
+    """model.py:964-1012: 5x5 'valid' convolutions, stride 1 then 3 (64-128-256-256-256-256), Dense 128 / 32 / 1.  fp32 only."""
+    return DiscriminatorStack(tuple(input_shape), (64, 128, 256, 256, 256, 256), activation, seed, "discriminator_sparse_512",
+                              kernel=5, strides=(1, 3, 3, 3, 3, 3), padding="valid", dense1=128)
 
 
 def make_discriminator_patchgan_70(input_shape, activation="none", norm="instance", seed=11, dtype="fp32"):
