@@ -435,13 +435,16 @@ def init_vgg19_features(seed=19, cin=3):
     return w
 
 
-def vgg19_block5_conv4(w, x_nhwc):
-    """VGG19 features: 3x3 'same' conv + ReLU stacks with 2x2/2 'valid' max pooling after blocks 1-4."""
+def vgg19_block5_conv4(w, x_nhwc, taps=None):
+    """VGG19 features: 3x3 'same' conv + ReLU stacks with 2x2/2 'valid' max pooling after blocks 1-4.  ``taps`` (optional list)
+    receives every convolution's ReLU output (NCHW) in order."""
     x = x_nhwc.permute(0, 3, 1, 2)
     for b, nconv, _ in VGG19_BLOCKS:
         for i in range(nconv):
             n = "block%d_conv%d" % (b, i + 1)
             x = torch.relu(K.conv2d(x, w[n + "/kernel"], w[n + "/bias"], 1, "same"))
+            if taps is not None:
+                taps.append(x)
         if b < 5:
             x = torch.nn.functional.max_pool2d(x, 2, 2)
     return x.permute(0, 2, 3, 1)

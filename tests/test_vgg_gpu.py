@@ -119,6 +119,72 @@ def test_generator_gradient_under_vgg_loss(rt, kind):
     report("generator gradient under %s: loss=%.5g worst tensor L2 err=%.2e" % (kind, lref, worst))
 
 
+@pytest.mark.parametrize("kind", ["vgg", "vgg_mse"])
+def test_generator_gradient_under_vgg_loss_with_oracle_masks(rt, kind):
+    """The same gradient with the mask-flip argument of the test above turned into a measurement: after the product's forward
+    pass every tensor it keeps for the backward pass (the generator's and the VGG19's saved activations -- what the ReLU / PReLU /
+    LeakyReLU / max-pool derivatives are decided from) is overwritten IN PLACE with the fp64 oracle's value of that tensor.  Both
+    backward passes then differentiate the same piecewise-linear function, and what is left is fp32 arithmetic: every gradient
+    tensor is held to 1e-3 (max-norm), as north_star states for fp32."""
+    from oracle import models as M, train as T
+    from upscaler import model as PM, _engine as E
+    w, V = _vgg_pair()
+    gw = M.init_upscaler_orig((64, 64, 3), 3, 64, 2, 1, seed=7)
+    for k in gw:
+        if k.endswith("/alpha"):
+            gw[k] = np.full_like(gw[k], 0.75)
+    G = PM.make_upscaler_orig((64, 64, 3), kernel_size=3, upscale_factor=2, res_block_num=1)
+    G.set_weights_dict(gw)
+    rate = 0.0 if kind == "vgg" else 0.1
+    x = (np.random.RandomState(1).randint(0, 256, (4, 32, 32, 3)) / 127.5 - 1).astype(np.float32)
+    t = (np.random.RandomState(2).randint(0, 256, (4, 64, 64, 3)) / 127.5 - 1).astype(np.float32)
+    # ---- oracle: loss, gradients and every intermediate tensor
+    leaf = M.to_torch(gw, torch.float64, requires_grad=True)
+    gt = {}
+    y, _ = M.upscaler_orig_forward(leaf, torch.tensor(x, dtype=torch.float64), True, 1, 2, taps=gt)
+    vt = []
+    vw = M.to_torch(w, torch.float64)
+    tt = torch.tensor(t, dtype=torch.float64)
+    f_fake, f_real = M.vgg19_block5_conv4(vw, y, vt), M.vgg19_block5_conv4(vw, tt)
+    loss = ((f_real - f_fake) ** 2).mean() + rate * ((tt - y) ** 2).mean()
+    names = [k for k, v in leaf.items() if v.requires_grad]
+    gref = dict(zip(names, torch.autograd.grad(loss, [leaf[k] for k in names])))
+    dev = lambda a: a.detach().float().to(rt.device).contiguous()
+    # ---- product forward, then the saved tensors <- the oracle's
+    fake, gtape = G.forward(E.to_device_nchw(rt, x), True)
+    hr = E.to_device_nchw(rt, t)
+    fr, _ = V.forward(hr)
+    ff, vtape = V.forward(fake)
+    fake.copy_(dev(y.permute(0, 3, 1, 2)))                               # G's output = VGG's input (and final/conv's saved tanh output)
+    order = ["initial/conv", "initial/prelu", "res_block/0/conv_pre", "res_block/0/prelu", "res_block/0/conv_post",
+             "res_block/0/final_add", None, "prefinal/tanh"]              # inputs of a_init, c1, n1, c2, n2, c_pre, n_pre, ups
+    for ctx, key in zip(gtape[1:9], order):
+        if key is not None:
+            ctx[0].copy_(dev(gt[key]))
+    gtape[8][1].copy_(dev(gt["upscaling/0/block/leaky_relu"]))            # the up-sampling block's saved LeakyReLU output
+    convs = [c for c in vtape if isinstance(c, tuple)]
+    assert len(convs) == len(vt) == 16
+    for ctx, a in zip(convs, vt):
+        ctx[1].copy_(dev(a))                                              # ReLU outputs (the pooling inputs are the same tensors)
+    ff.copy_(dev(f_fake.permute(0, 3, 1, 2)))
+    # ---- product backward from the loss
+    val, dfeat = PM._pixel_loss(rt, ff, fr, "mse", 1.0)
+    dfake = V.backward_data(vtape, dfeat)
+    if rate:
+        pval, dpix = PM._pixel_loss(rt, fake, hr, "mse", rate)
+        E.axpby(rt, dpix, dfake, 1.0, 1.0)
+    G.backward(gtape, dfake, 0)
+    gmax = max(float(g.abs().max()) for g in gref.values())
+    worst = 0.0
+    for k, b in gref.items():
+        a = G.ps.grad(k).cpu().double()
+        err = float((a - b).abs().max() / (b.abs().max() + 1e-4 * gmax))
+        worst = max(worst, err)
+        report("  %s (oracle masks) %-36s |g|=%.2e max-norm err=%.2e" % (kind, k, float(b.abs().max()), err))
+        assert err < TOL, (k, err)
+    report("generator gradient under %s with the oracle's saved activations: worst tensor max-norm err=%.2e" % (kind, worst))
+
+
 def test_gan_train_step_with_vgg_mse_loss(rt):
     """the reference's default loss form in the GAN step (train_gan3.py:267-272: VGG_MSE_LOSS), two iterations"""
     from oracle import models as M, train as T
