@@ -14,6 +14,7 @@
 // at -- but it serves every shape with one code path at several times the fp32 kernels' rate, and the data gradient of a
 // strided convolution is the same kernel run once per output phase with that phase's tap list.
 #include "vcg_common.hpp"
+#include <cstdlib>
 
 namespace {
 
@@ -204,7 +205,8 @@ int launch_gconv(GcParams& p, hipStream_t st) {
     const long tiles = (total + 31) / 32;
     // 4 tiles per wave (128 accumulator registers, half the operand loads per MFMA) once there is enough work to fill the chip
     const int mgroups = (p.mblocks + 1) / 2;
-    const bool big = tiles * mgroups >= 4096;
+    static const int force_nt = getenv("VCG_GCONV_NT") ? atoi(getenv("VCG_GCONV_NT")) : 0;       // tuning aid (scripts/kbench_gconv.py)
+    const bool big = force_nt ? force_nt == 4 : tiles * mgroups >= 4096;
     const int nt = big ? 4 : 2;
     const long wgs = (tiles + 4 * nt - 1) / (4 * nt);
     if (wgs > 0x7fffffffL) return VCG_E_SHAPE;
