@@ -55,6 +55,11 @@ def _worker(rank, world, port, q):
     _dist.allreduce_mean(m, group)
     w = torch.full((5,), float(rank))
     _dist.broadcast_(w, group, src=0)
+    # the trainer's form: SUM buckets, the 1/ranks folded into the consumer (Adam's grad_scale / vcg_gan_loss's mean_scale)
+    flat2, _ = _grads(lr[lo:hi], hr[lo:hi])
+    _dist.allreduce_sum(flat2, group)
+    assert _dist.world_size(group) == world
+    assert float((flat2 / world - flat).abs().max()) <= 1e-12 * max(float(flat.abs().max()), 1.0)
     if rank == 0:
         full, dfull = _grads(lr, hr)
         q.put((float((flat - full).abs().max()), float(full.abs().max()), abs(float(m) - dfull), (lo, hi)))
@@ -92,3 +97,4 @@ def test_shard_batch_single_process():
     assert _dist.shard_batch(8, None) == (0, 8)
     t = torch.ones(3)
     assert _dist.allreduce_mean(t, None) is t
+    assert _dist.allreduce_sum(t, None) is t and _dist.world_size(None) == 1

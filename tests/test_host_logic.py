@@ -48,8 +48,21 @@ def test_workspace_queries_and_argument_errors_without_gpu(built):
     assert 0 < ws < (1 << 30)
     assert lib.vcg_norm_stats_workspace_bytes(8, 64, 65536, 0) > 0
     assert lib.vcg_conv2d_fwd(None, None, None, None, None, None) == -1           # VCG_E_NULL
-    bad = built.ConvDesc(8, 64, 256, 256, 64, 256, 256, 3, 3, 3, 1, 1)            # stride 3
+    bad = built.ConvDesc(8, 64, 256, 256, 64, 256, 256, 3, 3, 4, 1, 1)            # stride 4: not instantiated
     assert lib.vcg_conv2d_wgrad_workspace_bytes(ctypes.byref(bad)) == 0
+    assert lib.vcg_conv2d_dgrad(ctypes.byref(bad), None, None, None, None, None, None) == -3       # VCG_E_UNSUPPORTED before any pointer is touched
+    # sparse_512's layer (model.py:971): 5x5, stride 3, 'valid'
+    sp = built.ConvDesc(8, 64, 508, 508, 128, 168, 168, 5, 5, 3, 0, 0)
+    assert lib.vcg_conv2d_wgrad_workspace_bytes(ctypes.byref(sp)) > 0
+    # generic bf16 convolution: PatchGAN block 4 (256 -> 512, 4x4, stride 1, pad 1)
+    g = built.ConvDesc(8, 256, 64, 64, 512, 63, 63, 4, 4, 1, 1, 1)
+    assert lib.vcg_conv2d_nhwc_bf16_wgrad_workspace_bytes(ctypes.byref(g)) > 0
+    assert lib.vcg_conv_frag_bf16_bytes(16, 512, 256) == 16 * 512 * 256 * 2
+    odd = built.ConvDesc(8, 48, 64, 64, 512, 63, 63, 4, 4, 1, 1, 1)               # 48 input channels: not a multiple of 64
+    assert lib.vcg_conv2d_nhwc_bf16_wgrad_workspace_bytes(ctypes.byref(odd)) == 0
+    assert lib.vcg_conv2d_nhwc_bf16_fwd(None, None, None, None, 0, 0.0, None, None) == -1
+    assert lib.vcg_head_act_fwd(None, None, 4, 1, None) == -1
+    assert lib.vcg_gan_loss(None, None, 1.0, 0, None, None, 0, 0.0, None, 0, 0.0, None) == -1
     with pytest.raises(ValueError):
         built.check(-2, "x")
 
@@ -66,6 +79,13 @@ def test_reference_signatures_are_mirrored():
     # :836, :901
     assert params(PM.make_discriminator_simple_512)[:2] == [("input_shape", inspect._empty), ("activation", "none")]
     assert params(PM.make_discriminator_thin_512)[:2] == [("input_shape", inspect._empty), ("activation", "none")]
+    # :964 and :299
+    assert params(PM.make_discriminator_sparse_512)[:2] == [("input_shape", inspect._empty), ("activation", "none")]
+    assert params(PM.make_upscaler_attention)[:5] == [("output_image_shape", inspect._empty), ("kernel_size", 5), ("filters", 64),
+                                                      ("upscale_factor", 4), ("res_block_num", 16)]
+    # the block functions, :30 and :78
+    assert [n for n, _ in params(PM.residual_block_attention)][:6] == ["model", "input_", "kernel_size", "filters", "strides", "batch_norm"]
+    assert [n for n, _ in params(PM.upsampling_block_attention)][:5] == ["model", "input_", "scale", "kernel_size", "filters"]
     # :1017-1027, :1057-1067
     names = [n for n, _ in params(PM.make_and_compile_gan)]
     assert names[:9] == ["generator", "discriminator", "input_shape", "output_shape", "content_loss", "content_loss_weight",
