@@ -70,6 +70,9 @@ CASES = [
     (1, 64, 64, False, "lrelu", True),
     (2, 5, 7, True, "prelu", True),           # smaller than one tile
     (9, 33, 31, True, "prelu", True),         # more tiles than one wave of workgroups can hold per CU
+    (16, 81, 97, True, "none", True),         # 384 tiles of 16x32: persistent workgroups take a second tile (double-buffered halo)
+    (10, 100, 100, False, "lrelu", False),    # 280 tiles: some workgroups take two, most one
+    (3, 200, 300, True, "prelu", False),      # 390 tiles, ragged on both edges
 ]
 
 

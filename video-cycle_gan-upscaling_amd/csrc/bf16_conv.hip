@@ -9,6 +9,7 @@
 // with the inference-mode BatchNormalization folded into a per-channel scale/shift (model.py:20,23,284),
 // PReLU (model.py:21) and the block's Add (model.py:25,285) fused into the epilogue.
 #include "vcg_common.hpp"
+#include <cstdlib>
 #include <utility>
 
 namespace {
@@ -16,6 +17,7 @@ namespace {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
     // lane l (r = l&31, h = l>>5): A[row r][k = 8h+j], B[k = 8h+j][col r], j = 0..7; D as the f32 form
@@ -327,6 +329,260 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_c64_bf16_kernel(C3Params p) {
                 }
         lds_barrier();                                   // B: the next tile is in LDS
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// v2 of the trunk convolution: weights in REGISTERS, halo tiles double-buffered by LDS-DMA, one wave per SIMD
+// ---------------------------------------------------------------------------------------------------------------
+// v1 keeps all 9x64x64 weights in LDS (72 KiB), which leaves room for ONE halo tile: hence its loader waves, its two
+// barriers per tile, the 2+1+1+2 placement of six compute waves on four SIMDs and one LDS read per MFMA.  Here the
+// workgroup is four waves, one per SIMD, each with the 512-register budget that buys:
+//   * a wave owns 32 of the 64 output channels x 8 of the 16 tile rows and keeps ITS 36 weight fragments (9 taps x 4
+//     channel groups) in 144 registers for the whole launch -- no weights in LDS at all;
+//   * LDS holds two 18x34-pixel halo tiles (2 x 76.5 KiB), filled by `buffer_load_dwordx4 ... lds` (range-checked by the
+//     buffer descriptor: the zero padding costs no branch and no select on data), issued two pieces per k-group under the
+//     MFMAs of the CURRENT tile;
+//   * for one (dx, channel group) the ten halo rows a wave needs are read ONCE and feed the MFMAs of all three dy:
+//     10 ds_read_b128 per 24 MFMAs (v1: 24), double-buffered in registers;
+//   * one barrier per tile; it orders LDS only, so the epilogue's stores drain under the next tile's MFMAs.
+// Measured (scripts/micro/v2_stamps.py, batch 32 at 256x256, sustained): 15.4 k cycles per tile = MFMA loop 72 % (11.1 k for
+// 9.2 k of MFMA issue), epilogue 26 %, barrier + wait 2 %; the matrix pipe is busy 60 % of the time (v1: 28 %) at the 1.63 GHz
+// the chip holds under this load (a bare v_mfma_f32_32x32x16_bf16 stream on random operands: 1.5-1.75 GHz, 1.5-1.75 PFLOP/s,
+// scripts/micro/mfma_peak_bf16.hip).  The variant WITH a residual input stays on v1: it moves 1.5x the bytes, and with
+// one wave per SIMD every stalled vector-memory issue also stalls that SIMD's MFMA stream (measured 0.234 ms against 0.213).
+constexpr int V2_TR = 16, V2_TC = 32, V2_HR = V2_TR + 2, V2_HC = V2_TC + 2;
+constexpr int V2_ROWB = V2_HC * 128;
+constexpr int V2_XB = V2_HR * V2_ROWB;                          // 78336
+constexpr int V2_NT = 256;
+constexpr int V2_CHUNKS = V2_XB / 16;                           // 4896 = 19 * 256 + 32
+constexpr int V2_NDMA = (V2_CHUNKS + V2_NT - 1) / V2_NT;        // 20 rounds; the last one is half of wave 0
+constexpr int V2_PAD = 512;                                     // what the other half of that wave writes (zeros) past the tile
+constexpr int V2_BUF = V2_XB + V2_PAD;
+constexpr int V2_LDS = 2 * V2_BUF + PB;
+static_assert(V2_LDS <= 160 * 1024, "v2 trunk kernel: LDS");
+static_assert(V2_NDMA == 20 && V2_CHUNKS - 19 * V2_NT == 32, "v2 trunk kernel: DMA schedule");
+
+struct TilePos { int y0, x0; vcg_rsrc rs; };     // halo origin and image descriptor of a tile
+
+// Diagnostic build only (-DVCG_V2_STAMPS, scripts/micro/v2_stamps.sh): s_memtime brackets around the four segments of a
+// tile, summed per wave in scalar registers and written to a buffer of their own after the loop.  No stamp executes in
+// the shipped library; read the SHARES of such a build, not its run time (cdna_hip_programming.md, In-kernel stamps).
+#ifdef VCG_V2_STAMPS
+__device__ unsigned long long vcg_v2_stamp_sums[256 * 4 * 6];
+#define V2_STAMP(t)                                                                   \
+    do {                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                            \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");     \
+        __builtin_amdgcn_sched_barrier(0);                                            \
+    } while (0)
+#define V2_STAMP_ADD(sum, a, b) sum += (b) - (a)
+#else
+#define V2_STAMP(t) do { } while (0)
+#define V2_STAMP_ADD(sum, a, b) do { } while (0)
+#endif
+
+template <bool AFF, bool SLOPE>
+__global__ __launch_bounds__(V2_NT, 1) void conv3x3_c64_bf16_v2_kernel(C3Params p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+#ifdef VCG_V2_STAMPS
+    const unsigned long long k_c0 = __builtin_amdgcn_s_memtime(), k_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    float* prm = (float*)(smem + 2 * V2_BUF);
+    const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, hh = lane >> 5;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int coh = wv & 1, rg = wv >> 1;                       // channel half, row group (rows 8rg .. 8rg+7 of the tile)
+
+    // this wave's 36 weight fragments: A[row = co][k = 8hh + j] of (tap, channel group s) = packed [tap][co][ci] chunk 2s + hh
+    bf16x8 wa[36];
+#pragma unroll
+    for (int i = 0; i < 36; ++i) {
+        const int tap = i >> 2, s = i & 3;
+        wa[i] = __builtin_bit_cast(bf16x8, p.w[(tap * 64 + coh * 32 + r) * 8 + 2 * s + hh]);
+    }
+    if (tid < 64) {
+        prm[tid] = p.scale ? p.scale[tid] : 1.f;
+        prm[64 + tid] = p.shift ? p.shift[tid] : 0.f;
+        prm[128 + tid] = p.act == VCG_ACT_PRELU ? p.alpha[tid] : (p.act == VCG_ACT_LRELU ? p.act_alpha : 1.f);
+    }
+    // LDS byte offset of lane (pixel r + dx, half hh)'s fragment of channel group s: boff[dx] ^ (s << 5) -- the swizzle XORs
+    // the chunk index 2s + hh with (pos >> 1) & 7, and 2s only touches bits 5-6 of the 128-byte row
+    int boff[3];
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+        const int pos = r + dx;
+        boff[dx] = rg * 8 * V2_ROWB + pos * 128 + ((hh ^ ((pos >> 1) & 7)) << 4);
+    }
+    const long img_bytes = (long)p.h * p.w_ * 128;
+
+    // one 4-KiB piece (round k of 20) of a tile's halo: slot = 16-byte chunk of the LDS image, in image order
+    auto locate = [&](int tile) {
+        const int txi = tile % p.tiles_x, t2 = tile / p.tiles_x, tyi = t2 % p.tiles_y, img = t2 / p.tiles_y;
+        return TilePos{tyi * V2_TR - 1, txi * V2_TC - 1, make_rsrc((const unsigned char*)p.x + img * img_bytes, (unsigned long)img_bytes)};
+    };
+    // (row, col) of a lane's slot advance by 32 pixels per round: kept incrementally (dma_row, dma_col), restarted per tile
+    // from an opaque copy of the lane id -- otherwise hipcc precomputes all 20 rounds into 50 registers this kernel lacks
+    int dma_row = 0, dma_col = 0;
+    auto dma_begin = [&]() {
+        int t = tid;
+        asm volatile("" : "+v"(t));
+        dma_row = (t >> 3) / V2_HC;
+        dma_col = (t >> 3) - dma_row * V2_HC;
+    };
+    auto dma = [&](const TilePos& tp, int buf, int k, bool live) {
+        const int row = dma_row, col = dma_col;
+        dma_col += 32;
+        if (dma_col >= V2_HC) dma_col -= V2_HC, ++dma_row;
+        if (k == V2_NDMA - 1 && wv != 0) return;                 // wave-uniform
+        const int sl = k * V2_NT + tid;
+        const int cs = (sl & 7) ^ ((col >> 1) & 7);                                // stored chunk (sl & 7) holds source chunk cs
+        const int gy = tp.y0 + row, gx = tp.x0 + col;
+        const bool ok = (unsigned)gy < (unsigned)p.h && (unsigned)gx < (unsigned)p.w_ && sl < V2_CHUNKS && live;
+        unsigned off = (unsigned)((gy * p.w_ + gx) * 128 + cs * 16);
+        asm volatile("" : "+v"(off));                            // a select, not a branch around the arithmetic (it would split the schedule)
+        off = ok ? off : VCG_OOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(tp.rs, (void __attribute__((address_space(3)))*)(smem + buf * V2_BUF + (k * V2_NT + wv * 64) * 16),
+                                                 16, off, 0, 0, 0);
+    };
+
+    bf16x8 fb[2][10];
+    auto frag = [&](const unsigned char* xb, int g, int b) {
+        const int dx = g >> 2, s = g & 3;
+#pragma unroll
+        for (int j = 0; j < 10; ++j) fb[b][j] = *(const bf16x8*)(xb + j * V2_ROWB + (boff[dx] ^ (s << 5)));
+    };
+
+    int tile = blockIdx.x, buf = 0;
+    if (tile < p.total) {
+        const TilePos tp = locate(tile);
+        dma_begin();
+#pragma unroll
+        for (int k = 0; k < V2_NDMA; ++k) dma(tp, 0, k, true);
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);                          // vmcnt(0): this wave's pieces have landed
+    lds_barrier();
+    if (tile < p.total) frag(smem, 0, 0);
+    unsigned long long st0 = 0, st1 = 0, st2 = 0, st3 = 0, st4 = 0, sum_mfma = 0, sum_wait = 0, sum_bar = 0, sum_epi = 0;
+    (void)st0, (void)st1, (void)st2, (void)st3, (void)st4, (void)sum_mfma, (void)sum_wait, (void)sum_bar, (void)sum_epi;
+
+    for (; tile < p.total; tile += gridDim.x, buf ^= 1) {
+        V2_STAMP(st0);
+        const int next = tile + gridDim.x;
+        const bool has_next = next < p.total;
+        const TilePos np = locate(has_next ? next : tile);
+        const unsigned char* xb = smem + buf * V2_BUF;
+        const int txi = tile % p.tiles_x, t2 = tile / p.tiles_x, tyi = t2 % p.tiles_y, img = t2 / p.tiles_y;
+        const int gx = txi * V2_TC + r, gy0 = tyi * V2_TR + rg * 8;
+        const bool okx = gx < p.w_;
+
+        f32x16 acc[8];
+#pragma unroll
+        for (int n = 0; n < 8; ++n)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[n][e] = 0.f;
+
+        // 12 k-groups (dx, s): ten halo rows -> 24 MFMAs (3 dy x 8 rows); group g+1's rows are read under group g's MFMAs
+        dma_begin();
+        // output stores go through a per-image buffer descriptor: an out-of-image lane gets the out-of-range offset instead
+        // of an exec mask (no branch around the store, and hipcc can count the stores in its vmcnt waits)
+        const vcg_rsrc yrs = make_rsrc((const unsigned char*)p.y + img * img_bytes, (unsigned long)img_bytes);
+        auto out_off = [&](int n, int q) {
+            const int gy = gy0 + n;
+            return gy < p.h && okx ? (unsigned)((gy * p.w_ + gx) * 128 + (coh * 32 + 16 * q + 8 * hh) * 2) : VCG_OOB;
+        };
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int g = 0; g < 12; ++g) {
+            const int cur = g & 1, dx = g >> 2, s = g & 3;
+            if (g + 1 < 12) frag(xb, g + 1, cur ^ 1);
+            if (g < 10) {
+                // unconditional (no branch to split the group's schedule): without a next tile the pieces are zeros into the idle buffer
+                dma(np, buf ^ 1, 2 * g, has_next);
+                dma(np, buf ^ 1, 2 * g + 1, has_next);
+            }
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int n = 0; n < 8; ++n) acc[n] = mfma_bf16(wa[(dy * 3 + dx) * 4 + s], fb[cur][n + dy], acc[n]);
+            if (g + 1 < 12) {
+                // 2 MFMAs, then one of the next group's reads, ten times; everything else of the group floats between them
+#pragma unroll
+                for (int j = 0; j < 10; ++j) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // The next tile's pieces were issued at least two k-groups ago: retire them, then the one barrier of the tile: every
+        // wave's pieces are in LDS and every wave is done reading this tile's image.  The epilogue comes AFTER it, so the
+        // waves drift apart there and the stores drain under the next tile's MFMAs.
+        V2_STAMP(st1);
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        V2_STAMP(st2);
+        lds_barrier();
+        V2_STAMP(st3);
+        __builtin_amdgcn_sched_barrier(0);
+
+        // epilogue: y = act(acc * scale + shift) -> bf16.  An MFMA tile leaves lane (pixel, h) with channels 8g+4h+{0..3};
+        // v_permlane32_swap between the register groups (2q, 2q+1) of the two half-waves turns that into 8 consecutive
+        // channels 16q+8h+{0..7}: 16-byte stores.
+        int prm_o = 0;
+        asm volatile("" : "+v"(prm_o));                  // re-read the parameters per tile: 48 registers not to be held across the MFMAs
+        const float* prm_t = prm + prm_o;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            if (q == 1) {
+                // the next tile's first rows, read under the second half of the epilogue
+                __builtin_amdgcn_sched_barrier(0);
+                if (has_next) frag(smem + (buf ^ 1) * V2_BUF, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            const int co = coh * 32 + 16 * q + 8 * hh;
+            float sc[8], sh[8], al[8];
+            if (AFF) {
+                *(f32x4*)&sc[0] = *(const f32x4*)(prm_t + co);
+                *(f32x4*)&sc[4] = *(const f32x4*)(prm_t + co + 4);
+                *(f32x4*)&sh[0] = *(const f32x4*)(prm_t + 64 + co);
+                *(f32x4*)&sh[4] = *(const f32x4*)(prm_t + 64 + co + 4);
+            }
+            if (SLOPE) {
+                *(f32x4*)&al[0] = *(const f32x4*)(prm_t + 128 + co);
+                *(f32x4*)&al[4] = *(const f32x4*)(prm_t + 128 + co + 4);
+            }
+#pragma unroll
+            for (int n = 0; n < 8; ++n) {
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float lo = acc[n][8 * q + j], hi = acc[n][8 * q + 4 + j];
+                    swap32(lo, hi);
+                    v[j] = lo;
+                    v[4 + j] = hi;
+                }
+                bf16x8 ov;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    float u = v[j];
+                    if (AFF) u = u * sc[j] + sh[j];
+                    if (SLOPE) u = u >= 0.f ? u : u * al[j];
+                    ov[j] = (__bf16)u;
+                }
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ov), yrs, (int)out_off(n, q), 0, 0);
+            }
+        }
+        V2_STAMP(st4);
+        V2_STAMP_ADD(sum_mfma, st0, st1);
+        V2_STAMP_ADD(sum_wait, st1, st2);
+        V2_STAMP_ADD(sum_bar, st2, st3);
+        V2_STAMP_ADD(sum_epi, st3, st4);
+    }
+#ifdef VCG_V2_STAMPS
+    if (lane == 0) {
+        unsigned long long* o = vcg_v2_stamp_sums + (blockIdx.x * 4 + wv) * 6;
+        o[0] = sum_mfma, o[1] = sum_wait, o[2] = sum_bar, o[3] = sum_epi;
+        o[4] = __builtin_amdgcn_s_memtime() - k_c0, o[5] = __builtin_amdgcn_s_memrealtime() - k_r0;     // whole kernel: core clock / 100 MHz
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -956,8 +1212,35 @@ int vcg_conv2d_bf16_fwd(const vcg_conv_desc* d, const void* x, const void* w_pac
             }
             attr_set = true;
         }
-        const int grid = p.total < 256 ? p.total : 256;
         const bool aff = p.scale || p.shift, slope = act != VCG_ACT_NONE, res = p.res != nullptr;
+        // v2 (one wave per SIMD, weights in registers) unless there is a residual input or the image is too large for one
+        // buffer descriptor; VCG_CONV3X3_V1=1 forces v1 (A/B aid: scripts/gpu_v2_ab.sh)
+        static const bool use_v1 = getenv("VCG_CONV3X3_V1") != nullptr;
+        if (!use_v1 && !res && (long)d->h * d->w * 128 <= 0xFFFFFFE0l) {
+            p.tiles_x = ceil_div(d->w, V2_TC);
+            p.tiles_y = ceil_div(d->h, V2_TR);
+            p.total = p.n * p.tiles_x * p.tiles_y;
+            static bool attr2_set = false;
+            if (!attr2_set) {
+                for (auto f : {(const void*)conv3x3_c64_bf16_v2_kernel<false, false>, (const void*)conv3x3_c64_bf16_v2_kernel<false, true>,
+                               (const void*)conv3x3_c64_bf16_v2_kernel<true, false>, (const void*)conv3x3_c64_bf16_v2_kernel<true, true>}) {
+                    hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, V2_LDS);
+                    if (e != hipSuccess) return (int)e;
+                }
+                attr2_set = true;
+            }
+            const int grid2 = p.total < 256 ? p.total : 256;
+#define VCG_C3V2_LAUNCH(A, S) conv3x3_c64_bf16_v2_kernel<A, S><<<grid2, V2_NT, V2_LDS, stream>>>(p)
+            if (aff) {
+                if (slope) VCG_C3V2_LAUNCH(true, true); else VCG_C3V2_LAUNCH(true, false);
+            } else {
+                if (slope) VCG_C3V2_LAUNCH(false, true); else VCG_C3V2_LAUNCH(false, false);
+            }
+#undef VCG_C3V2_LAUNCH
+            VCG_LAUNCH_CHECK();
+            return VCG_OK;
+        }
+        const int grid = p.total < 256 ? p.total : 256;
 #define VCG_C3_LAUNCH(A, S, R) conv3x3_c64_bf16_kernel<A, S, R><<<grid, NT, WB + XB + PB, stream>>>(p)
         if (aff) {
             if (slope) { if (res) VCG_C3_LAUNCH(true, true, true); else VCG_C3_LAUNCH(true, true, false); }
@@ -1124,3 +1407,11 @@ int vcg_conv9x9_to3_bf16_dgrad(const vcg_conv_desc* d, const void* dy, const voi
 }
 
 }  // extern "C"
+
+#ifdef VCG_V2_STAMPS
+// diagnostic build only: copy the per-wave sums [256 workgroups][4 waves][mfma, wait, barrier, epilogue, kernel core clocks, kernel 100-MHz ticks] to the host
+extern "C" int vcg_debug_v2_stamps(unsigned long long* host_out) {
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(vcg_v2_stamp_sums), sizeof(unsigned long long) * 256 * 4 * 6);
+}
+#endif
