@@ -174,6 +174,26 @@ int vcg_atanh_scale(const float* x, float* y, size_t count, float scale, vcg_str
  * stride-3 convolution (make_discriminator_sparse_512, upscaling/upscaler/model.py:971-987) = vcg_conv2d_dgrad with stride 1 over
  * the dilated gradient. */
 int vcg_dilate2d(const float* src, float* dst, size_t planes, int h, int w, int stride, vcg_stream_t stream);
+/* Lambda(K.resize_images(x, f, f, 'channels_last', 'nearest' | 'bilinear')) of the skip-connection / attention / U-Net-ish
+ * generators (upscaling/upscaler/model.py:80-81,352,705,786) with Keras 2.2.x on TF 1.14 semantics: tf.image.resize_nearest_neighbor /
+ * resize_bilinear, align_corners=False, no half-pixel centres (source coordinate = destination / f).  dst: planes x (h*f) x (w*f).
+ * Forward only: every use in the reference resizes the network INPUT, which is data. */
+int vcg_resize2d(const float* src, float* dst, size_t planes, int h, int w, int factor, int bilinear, vcg_stream_t stream);
+/* Cropping2D(((top, bottom), (left, right))) (model.py:552,563,626): dst[pl][y][x] = src[pl][y + top][x + left], dst oh x ow */
+int vcg_crop2d(const float* src, float* dst, size_t planes, int h, int w, int top, int left, int oh, int ow, vcg_stream_t stream);
+/* its gradient: dst (oh x ow) holds src (h x w) at offset (top, left), zeros elsewhere */
+int vcg_pad2d(const float* src, float* dst, size_t planes, int h, int w, int top, int left, int oh, int ow, vcg_stream_t stream);
+/* Concatenate(axis=3) (model.py:353,406,435,553) and its gradient in NCHW = block copies of channels:
+ * dst[n][c_dst_off + c][hw] = src[n][c_src_off + c][hw], c < c_count (src has c_src channels per image, dst c_dst) */
+int vcg_copy_channels(const float* src, float* dst, int n, int c_src, int c_src_off, int c_dst, int c_dst_off, int c_count, size_t hw,
+                      vcg_stream_t stream);
+/* Dropout(rate) in the learning phase (model.py:510,519,528): keep = u >= rate with u a counter-based hash of (seed, *step, element
+ * index) -- *step is read on the device so a recorded hipGraph draws a new mask per replay (vcg_counter_inc advances it);
+ * y = keep ? x / (1 - rate) : 0 (tf.nn.dropout); the mask (1 byte per element) is written for the backward: dx = dy * mask / (1 - rate) */
+int vcg_dropout_fwd(const float* x, float* y, unsigned char* mask, size_t count, float rate, unsigned long long seed,
+                    const unsigned long long* step, vcg_stream_t stream);
+int vcg_dropout_bwd(const float* dy, const unsigned char* mask, float* dx, size_t count, float rate, vcg_stream_t stream);
+int vcg_counter_inc(unsigned long long* counter, vcg_stream_t stream);
 /* y = value everywhere (broadcast gradient of a mean) */
 int vcg_fill(float* y, size_t count, float value, vcg_stream_t stream);
 /* y = a*x + b*y */

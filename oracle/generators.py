@@ -1,0 +1,234 @@
+"""ORACLE -- TEST INFRASTRUCTURE ONLY.  PARITY UNPINNED (see oracle/keras_ops.py header).
+
+CPU restatement of the other generator topologies train_gan3.py offers behind ``-gm`` (upscaling/train_gan3.py:55,234-252):
+  make_upscaler_skip_con          upscaling/upscaler/model.py:332-363
+  make_upscaler_unetish           upscaling/upscaler/model.py:570-634   (blocks :505-566)
+  make_upscaler_unetish_add       upscaling/upscaler/model.py:642-716
+  make_upscaler_unetish_complex   upscaling/upscaler/model.py:743-827
+
+Written define-by-run: ``Net`` looks every layer's weights up by its Keras name in a flat dict (the weight-exchange format of
+oracle/models.py); run with ``rng`` set, missing weights are created the way Keras initialises them, so one function both counts /
+initialises the parameters and evaluates the network.  Unnamed layers get Keras' automatic names (conv2d_1, batch_normalization_3,
+p_re_lu_1 ...: keras.backend.get_uid per class, counted from 1 in a fresh session).  Dropout is restated as tf.nn.dropout GIVEN the
+keep-mask (x * mask / (1 - rate)): the reference's random stream is not reproducible, the arithmetic is.
+"""
+import math
+from collections import OrderedDict
+
+import torch
+
+from . import keras_ops as K
+from . import models as M
+
+
+class Net:
+    def __init__(self, w, training, rng=None, masks=None):
+        self.w, self.training, self.rng, self.masks = w, training, rng, masks or {}
+        self.uid = {}
+        self.names = set()
+        self.upd = OrderedDict()          # moving statistics after the step (learning phase 1)
+        self.dtype = torch.float64
+
+    # -- names ------------------------------------------------------------------------------------------
+    def _name(self, name, cls):
+        if not name:
+            self.uid[cls] = self.uid.get(cls, 0) + 1
+            name = "%s_%d" % (cls, self.uid[cls])
+        if name in self.names:
+            # keras.engine.network.Network._init_graph_network: all layer names should be unique
+            raise ValueError('The name "%s" is used more than once in the model. All layer names should be unique.' % name)
+        self.names.add(name)
+        return name
+
+    def _get(self, key, make):
+        if key not in self.w:
+            if self.rng is None:
+                raise KeyError(key)
+            tmp = OrderedDict()
+            make(tmp)
+            for k, v in tmp.items():
+                self.w[k] = torch.tensor(v, dtype=self.dtype)
+        return self.w[key]
+
+    # -- layers -------------------------------------------------------------------------------------------
+    def conv2d(self, x, filters, k, stride=1, name=None):
+        n = self._name(name, "conv2d")
+        cin = x.shape[1]
+        self._get(n + "/kernel", lambda t: M._conv_w(t, self.rng, n, k, k, cin, filters))
+        return K.conv2d(x, self.w[n + "/kernel"], self.w[n + "/bias"], stride, "same")
+
+    def conv2d_transpose(self, x, filters, k, stride=2, name=None):
+        n = self._name(name, "conv2d_transpose")
+        cin = x.shape[1]
+        self._get(n + "/kernel", lambda t: M._convt_w(t, self.rng, n, k, k, cin, filters))
+        return K.conv2d_transpose_same(x, self.w[n + "/kernel"], self.w[n + "/bias"], stride)
+
+    def bn(self, x, name=None):
+        n = self._name(name, "batch_normalization")
+        c = x.shape[1]
+        self._get(n + "/gamma", lambda t: M._bn_w(t, n, c))
+        y, mm, mv = K.batchnorm(x, self.w[n + "/gamma"], self.w[n + "/beta"], self.w[n + "/moving_mean"], self.w[n + "/moving_variance"], self.training)
+        if self.training:
+            self.upd[n + "/moving_mean"], self.upd[n + "/moving_variance"] = mm, mv
+        return y
+
+    def prelu(self, x, name=None):
+        n = self._name(name, "p_re_lu")
+        c = x.shape[1]
+        self._get(n + "/alpha", lambda t: M._prelu_w(t, n, c))
+        return K.prelu(x, self.w[n + "/alpha"])
+
+    def dropout(self, x, rate, name=None):
+        n = self._name(name, "dropout")
+        if not self.training or not 0.0 < rate < 1.0:          # keras.layers.Dropout.call
+            return x
+        return x * self.masks[n].to(x.dtype) / (1.0 - rate)      # tf.nn.dropout with the given keep-mask
+
+    @staticmethod
+    def crop(x, cropping):
+        (t, b), (l, r) = cropping
+        return x[:, :, t:x.shape[2] - b, l:x.shape[3] - r]
+
+
+# ---- model.py:15-27, 70-75 -------------------------------------------------------------------------------------
+def residual_block(net, model, kernel_size, filters, strides, name=""):
+    gen = model
+    model = net.conv2d(model, filters, kernel_size, strides, name + "/conv_pre")
+    model = net.bn(model, name + "/batch_norm_pre")
+    model = net.prelu(model, name + "/prelu")
+    model = net.conv2d(model, filters, kernel_size, strides, name + "/conv_post")
+    model = net.bn(model, name + "/batch_norm_post")
+    net._name(name + "/final_add", "add")
+    return gen + model
+
+
+def upsampling_block(net, model, kernel_size, filters, strides, name=""):
+    model = net.conv2d_transpose(model, filters, kernel_size, strides, name + "/conv_transp")
+    net._name(name + "/leaky_relu", "leaky_re_lu")
+    return K.leaky_relu(model, 0.2)
+
+
+def upscaler_skip_con(net, x_nhwc, kernel_size=5, filters=64, upscale_factor=4, unique_names=False):
+    """model.py:332-363 ([N,h,w,3] -> [N,h*f,w*f,3]); with unique_names=False it raises like Keras does (sixteen '/conv_pre')"""
+    x = x_nhwc.permute(0, 3, 1, 2)
+    upscale_times = int(math.log(upscale_factor, 2))
+    model = net.prelu(net.conv2d(x, 64, 9, 1))
+    upsc_model = model
+    for index in range(16):
+        model = residual_block(net, model, kernel_size, filters, 1, "res_block/%d" % index if unique_names else "")
+    model = net.bn(net.conv2d(model, 64, 3, 1))
+    model = upsc_model + model
+    for index in range(upscale_times):
+        model = upsampling_block(net, model, 3, 224, 2, "upscaling/%d/block" % index if unique_names else "")
+    resized_input = M.resize_images_tf1(x, 2 ** upscale_times, "bilinear")
+    model = torch.cat([resized_input, model], 1)
+    model = torch.tanh(net.conv2d(model, 3, 9, 1))
+    return model.permute(0, 2, 3, 1)
+
+
+# ---- model.py:505-566 ------------------------------------------------------------------------------------------
+def same_size_unetish_block(net, model, kernel_size, filters, strides, name, dropout_rate=0.1):
+    model = net.conv2d(model, filters, kernel_size, strides, name + "/Conv2D")
+    model = net.bn(model)
+    model = net.prelu(model, name + "/PReLU")
+    return net.dropout(model, dropout_rate, name + "/Dropout")
+
+
+def upsampling_unetish_block(net, model, kernel_size, filters, strides, name, dropout_rate=0.1):
+    model = net.conv2d_transpose(model, filters, kernel_size, strides, name + "/Conv2DTrans")
+    model = net.bn(model)
+    model = net.prelu(model, name + "/PReLU")
+    return net.dropout(model, dropout_rate, name + "/Dropout")
+
+
+def find_crop_shape(output_down, output_up):
+    height_diff, width_diff = output_up.shape[2] - output_down.shape[2], output_up.shape[3] - output_down.shape[3]
+    top_crop, left_crop = height_diff // 2, width_diff // 2
+    return ((top_crop, height_diff - top_crop), (left_crop, width_diff - left_crop))
+
+
+def concatenate_layers(output_down, output_up):
+    return torch.cat([output_down, Net.crop(output_up, find_crop_shape(output_down, output_up))], 1)
+
+
+def sum_layers(output_down, output_up):
+    return output_down + Net.crop(output_up, find_crop_shape(output_down, output_up))
+
+
+def _u(net, x, kernel_size, upscale_factor, step_size, downscale_times, initial_step_filter_count, dropout_rate, join, halve_after_bottom):
+    upscale_times = int(math.log(upscale_factor, 2)) + downscale_times
+    model = net.prelu(net.conv2d(x, initial_step_filter_count, 9, 1, "initial/Conv2D"), "initial/PReLU")
+    outputs, step_filter_count, step = [], initial_step_filter_count, 0
+    for step in range(downscale_times):
+        for index in range(step_size):
+            model = same_size_unetish_block(net, model, kernel_size, step_filter_count, 1, "down/%d/same/%d" % (step, index))      # rate 0.1 (:590)
+        outputs.append(model)
+        model = same_size_unetish_block(net, model, kernel_size, step_filter_count, 2, "down/%d/down" % step, dropout_rate)
+        step_filter_count *= 2
+    for index in range(step_size):
+        model = same_size_unetish_block(net, model, kernel_size, step_filter_count, 1, "bottom/%d/same/%d" % (step, index), dropout_rate)
+    if halve_after_bottom:
+        step_filter_count //= 2
+    for step in range(upscale_times):
+        model = upsampling_unetish_block(net, model, kernel_size, step_filter_count, 2, "up/%d/up" % step, dropout_rate)
+        if step < len(outputs):
+            model = join(outputs[len(outputs) - step - 1], model)
+            step_filter_count //= 2
+        for index in range(step_size):
+            model = same_size_unetish_block(net, model, kernel_size, step_filter_count, 1, "up/%d/same/%d" % (step, index), dropout_rate)
+    return model
+
+
+def _final_crop(model, out_h, out_w):
+    height_diff, width_diff = model.shape[2] - out_h, model.shape[3] - out_w
+    top_crop, left_crop = height_diff // 2, width_diff // 2
+    return Net.crop(model, ((top_crop, height_diff - top_crop), (left_crop, width_diff - left_crop)))
+
+
+def upscaler_unetish(net, x_nhwc, kernel_size=5, upscale_factor=4, step_size=4, downscale_times=5, initial_step_filter_count=32, dropout_rate=0.1):
+    """model.py:570-634"""
+    x = x_nhwc.permute(0, 3, 1, 2)
+    model = _u(net, x, kernel_size, upscale_factor, step_size, downscale_times, initial_step_filter_count, dropout_rate, concatenate_layers, False)
+    model = torch.tanh(net.conv2d(model, 3, 9, 1))
+    return _final_crop(model, x.shape[2] * upscale_factor, x.shape[3] * upscale_factor).permute(0, 2, 3, 1)
+
+
+def upscaler_unetish_add(net, x_nhwc, kernel_size=5, upscale_factor=4, step_size=4, downscale_times=5, initial_step_filter_count=48, dropout_rate=0.1):
+    """model.py:642-716"""
+    x = x_nhwc.permute(0, 3, 1, 2)
+    model = _u(net, x, kernel_size, upscale_factor, step_size, downscale_times, initial_step_filter_count, dropout_rate, sum_layers, True)
+    model = torch.tanh(net.conv2d(model, 3, 9, 1))
+    model = _final_crop(model, x.shape[2] * upscale_factor, x.shape[3] * upscale_factor)
+    resized_input = torch.atanh(0.99999 * M.resize_images_tf1(x, upscale_factor, "bilinear"))
+    model = sum_layers(model, resized_input)
+    return torch.tanh(net.conv2d(model, 3, 9, 1)).permute(0, 2, 3, 1)
+
+
+def upscaler_unetish_complex(net, x_nhwc, kernel_size=5, upscale_factor=4, step_size=4, downscale_times=3, initial_step_filter_count=32,
+                             dropout_rate=0.1):
+    """model.py:743-827"""
+    x = x_nhwc.permute(0, 3, 1, 2)
+    model = _u(net, x, kernel_size, upscale_factor, step_size, downscale_times, initial_step_filter_count, dropout_rate, concatenate_layers, False)
+    resized_input = M.resize_images_tf1(x, upscale_factor, "bilinear")
+    attention = net.conv2d(resized_input, 3, 9, 1, "final/initial/attention")
+    for step in range(3):
+        p = "final/%d" % step
+        attention = torch.cat([resized_input, attention], 1)
+        attention = torch.sigmoid(net.conv2d(attention, 3, 9, 1, p + "/attention"))
+        model = net.conv2d(model, 3, 9, 1, p + "/Conv2D")
+        att_model = attention * model
+        model = torch.cat([att_model, model], 1)
+        model = torch.tanh(net.conv2d(model, 3, 9, 1, p + "/Conv2D_after_att"))
+        if step < 2:
+            model = net.dropout(model, dropout_rate, p + "/Dropout")
+    return _final_crop(model, x.shape[2] * upscale_factor, x.shape[3] * upscale_factor).permute(0, 2, 3, 1)
+
+
+def init_weights(fn, in_shape, seed, **kw):
+    """run ``fn`` once on zeros with weight creation enabled: {name: float32 array} in creation (= Keras layer) order"""
+    import numpy as np
+    w = OrderedDict()
+    net = Net(w, False, rng=np.random.RandomState(seed))
+    with torch.no_grad():
+        fn(net, torch.zeros((1,) + tuple(in_shape), dtype=torch.float64), **kw)
+    return OrderedDict((k, v.numpy().astype(np.float32)) for k, v in w.items())

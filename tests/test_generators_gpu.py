@@ -1,0 +1,129 @@
+"""The other generator topologies train_gan3.py offers behind -gm (upscaling/train_gan3.py:55,234-252; upscaler/model.py:332-363,
+505-827) on the device engine against their fp64 oracle restatements (oracle/generators.py): parameter count and names, inference,
+learning-phase forward (Dropout: same keep-masks on both sides), every parameter gradient, moving statistics.  Frame sizes are odd
+where the topology crops (U-Net-ish joins: 11 -> 6 -> 12 -> crop 11)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err, report
+
+pytestmark = pytest.mark.gpu
+
+
+def _randomise(gw, seed):
+    rng = np.random.RandomState(seed)
+    for n_, v in gw.items():                              # non-trivial BN / PReLU parameters
+        if n_.endswith(("/bias", "/beta", "/moving_mean")):
+            gw[n_] = rng.uniform(-0.1, 0.1, v.shape).astype(np.float32)
+        elif n_.endswith(("/gamma", "/moving_variance")):
+            gw[n_] = rng.uniform(0.8, 1.2, v.shape).astype(np.float32)
+        elif n_.endswith("/alpha"):
+            gw[n_] = rng.uniform(0.0, 0.3, v.shape).astype(np.float32)
+    return gw
+
+
+def _check(rt, tag, product, oracle_fn, okw, in_hw, out_hw, seed):
+    from oracle import generators as OG, models as M
+    from upscaler import _engine as E, model as PM
+    gw = _randomise(OG.init_weights(oracle_fn, in_hw + (3,), seed, **okw), seed + 1)
+    assert product.count_params() == M.count_params(gw)
+    assert set(product.get_weights_dict()) == set(gw)
+    assert product.input_shape == (None,) + in_hw + (3,) and product.output_shape == (None,) + out_hw + (3,)
+    product.set_weights_dict(gw)
+    rng = np.random.RandomState(seed + 2)
+    x = (rng.randint(0, 256, (2,) + in_hw + (3,)) / 127.5 - 1).astype(np.float32)
+    t = (rng.randint(0, 256, (2,) + out_hw + (3,)) / 127.5 - 1).astype(np.float32)
+    with torch.no_grad():
+        y0 = oracle_fn(OG.Net(M.to_torch(gw, torch.float64), False), torch.tensor(x, dtype=torch.float64), **okw)
+    e0 = rel_err(torch.tensor(product.predict(x)), y0)
+
+    yd, tape = product.forward(E.to_device_nchw(rt, x), True)
+    masks = {k: v.cpu() for k, v in product.dropout_masks(tape).items()}
+    for k, m in masks.items():
+        keep = float(m.float().mean())
+        assert 0.8 < keep < 0.97 or m.numel() < 2000, (k, keep)          # rate 0.1
+
+    def run(dtype):
+        leaf = M.to_torch(gw, dtype, requires_grad=True)
+        net = OG.Net(leaf, True, masks=masks)
+        y = oracle_fn(net, torch.tensor(x, dtype=dtype), **okw)
+        names = [n_ for n_, v in leaf.items() if v.requires_grad]
+        loss = ((y - torch.tensor(t, dtype=dtype)) ** 2).mean()
+        return y, net.upd, names, dict(zip(names, torch.autograd.grad(loss, [leaf[n_] for n_ in names])))
+
+    y, upd, names, grads = run(torch.float64)
+    _, _, _, g32 = run(torch.float32)
+    e1 = rel_err(E.to_nhwc(rt, yd), y)
+    val, dy = PM._pixel_loss(rt, yd, E.to_device_nchw(rt, t), "mse", 1.0)
+    product.backward(tape, dy, 0)
+    gmax = max(float(g.abs().max()) for g in grads.values())
+    worst, worst_name = 0.0, None
+    for n_ in names:
+        a, b = product.ps.grad(n_).cpu().double().reshape(grads[n_].shape), grads[n_]
+        err = float((a - b).abs().max() / (b.abs().max() + 1e-4 * gmax))
+        e32 = float((g32[n_].double() - b).abs().max() / (b.abs().max() + 1e-4 * gmax))
+        if err > worst:
+            worst, worst_name = err, n_
+        assert err < max(1e-3, 4 * e32), (n_, err, e32)
+    sw = product.get_weights_dict()
+    for n_, v in upd.items():
+        assert np.max(np.abs(sw[n_] - v.detach().numpy())) < 1e-4 * (np.max(np.abs(v.detach().numpy())) + 1e-3), n_
+    report("%s: %d params, %d dropout layers; predict err=%.2e train fwd err=%.2e worst gradient err=%.2e (%s)"
+           % (tag, product.count_params(), len(masks), e0, e1, worst, worst_name))
+    assert e0 < 1e-3 and e1 < 1e-3
+
+
+U = dict(kernel_size=3, upscale_factor=2, step_size=1, downscale_times=2, initial_step_filter_count=32, dropout_rate=0.1)
+
+
+def test_unetish_matches_oracle(rt):
+    from oracle import generators as OG
+    from upscaler import model as PM
+    _check(rt, "make_upscaler_unetish", PM.make_upscaler_unetish((44, 60, 3), **U), OG.upscaler_unetish, U, (22, 30), (44, 60), 3)
+
+
+def test_unetish_add_matches_oracle(rt):
+    from oracle import generators as OG
+    from upscaler import model as PM
+    _check(rt, "make_upscaler_unetish_add", PM.make_upscaler_unetish_add((44, 60, 3), **U), OG.upscaler_unetish_add, U, (22, 30), (44, 60), 5)
+
+
+def test_unetish_complex_matches_oracle(rt):
+    from oracle import generators as OG
+    from upscaler import model as PM
+    _check(rt, "make_upscaler_unetish_complex", PM.make_upscaler_unetish_complex((44, 60, 3), **U), OG.upscaler_unetish_complex, U, (22, 30), (44, 60), 7)
+
+
+def test_unetish_x4_default_depth_shapes(rt):
+    """the reference's defaults (kernel 5, x4, five down-samplings, step size 4) at a small frame: builds, crops to the requested output"""
+    from upscaler import model as PM
+    G = PM.make_upscaler_unetish((72, 104, 3), step_size=1)
+    assert G.input_shape == (None, 18, 26, 3) and G.output_shape == (None, 72, 104, 3)
+    x = (np.random.RandomState(0).randint(0, 256, (1, 18, 26, 3)) / 127.5 - 1).astype(np.float32)
+    y = G.predict(x)
+    assert y.shape == (1, 72, 104, 3) and np.isfinite(y).all() and np.abs(y).max() <= 1.0
+
+
+def test_skip_con_matches_oracle_and_mirrors_the_reference_error(rt):
+    from oracle import generators as OG
+    from upscaler import model as PM
+    with pytest.raises(ValueError, match="unique"):                     # what keras.engine.network does with sixteen '/conv_pre'
+        PM.make_upscaler_skip_con((32, 48, 3), kernel_size=3, upscale_factor=2)
+    kw = dict(kernel_size=3, upscale_factor=2, unique_names=True)
+    _check(rt, "make_upscaler_skip_con", PM.make_upscaler_skip_con((32, 48, 3), **kw), OG.upscaler_skip_con, kw, (16, 24), (32, 48), 9)
+
+
+def test_dropout_masks_change_every_step_and_vanish_at_inference(rt):
+    from upscaler import _engine as E, model as PM
+    G = PM.make_upscaler_unetish((44, 60, 3), **U)
+    x = E.to_device_nchw(rt, (np.random.RandomState(1).randint(0, 256, (2, 22, 30, 3)) / 127.5 - 1).astype(np.float32))
+    _, t1 = G.forward(x, True)
+    _, t2 = G.forward(x, True)
+    m1, m2 = G.dropout_masks(t1), G.dropout_masks(t2)
+    assert m1 and set(m1) == set(m2)
+    assert all(not torch.equal(m1[k], m2[k]) for k in m1)
+    _, t0 = G.forward(x, False)
+    assert not G.dropout_masks(t0)
+    a, b = G.predict(x.permute(0, 2, 3, 1).cpu().numpy()), G.predict(x.permute(0, 2, 3, 1).cpu().numpy())
+    assert np.array_equal(a, b)

@@ -96,13 +96,15 @@ def test_custom_generator_with_downsampling_block_matches_oracle(rt):
     assert e_f < 1e-3 and worst < 5e-3
 
 
-def test_upscaler_attention_matches_oracle(rt):
-    """make_upscaler_attention (model.py:299-328), train_gan3.py's default generator, at upscale_factor=2: parameter count,
-    inference and training-mode forward, every parameter gradient against the fp64 oracle (autograd)."""
+@pytest.mark.parametrize("factor", [2, 4])
+def test_upscaler_attention_matches_oracle(rt, factor):
+    """make_upscaler_attention (model.py:299-328), train_gan3.py's default generator, at upscale_factor 2 (BASELINE.json's) and 4
+    (train_gan3.py's default -d; the second up-sampling block resizes the input x2 and transposes it with strides 4): parameter
+    count, inference and training-mode forward, every parameter gradient against the fp64 oracle (autograd)."""
     from oracle import models as M
     from upscaler import _engine as E, model as PM
     out_shape, res, k = (64, 96, 3), 3, 3
-    gw = M.init_upscaler_attention(out_shape, k, 64, 2, res, seed=5)
+    gw = M.init_upscaler_attention(out_shape, k, 64, factor, res, seed=5)
     rng = np.random.RandomState(2)
     for n_, v in gw.items():                              # non-trivial BN / PReLU parameters
         if n_.endswith(("/bias", "/beta", "/moving_mean")):
@@ -111,22 +113,22 @@ def test_upscaler_attention_matches_oracle(rt):
             gw[n_] = rng.uniform(0.8, 1.2, v.shape).astype(np.float32)
         elif n_.endswith("/alpha"):
             gw[n_] = rng.uniform(0.0, 0.3, v.shape).astype(np.float32)
-    G = PM.make_upscaler_attention(out_shape, kernel_size=k, upscale_factor=2, res_block_num=res)
+    G = PM.make_upscaler_attention(out_shape, kernel_size=k, upscale_factor=factor, res_block_num=res)
     assert G.count_params() == M.count_params(gw)
-    assert G.input_shape == (None, 32, 48, 3) and G.output_shape == (None, 64, 96, 3)
+    assert G.input_shape == (None, 64 // factor, 96 // factor, 3) and G.output_shape == (None, 64, 96, 3)
     G.set_weights_dict(gw)
-    x = (rng.randint(0, 256, (2, 32, 48, 3)) / 127.5 - 1).astype(np.float32)
+    x = (rng.randint(0, 256, (2, 64 // factor, 96 // factor, 3)) / 127.5 - 1).astype(np.float32)
     t = (rng.randint(0, 256, (2, 64, 96, 3)) / 127.5 - 1).astype(np.float32)
     with torch.no_grad():
-        y0, _ = M.upscaler_attention_forward(M.to_torch(gw, torch.float64), torch.tensor(x, dtype=torch.float64), False, res, 2)
+        y0, _ = M.upscaler_attention_forward(M.to_torch(gw, torch.float64), torch.tensor(x, dtype=torch.float64), False, res, factor)
     e0 = rel_err(torch.tensor(G.predict(x)), y0)
     leaf = M.to_torch(gw, torch.float64, requires_grad=True)
-    y, upd = M.upscaler_attention_forward(leaf, torch.tensor(x, dtype=torch.float64), True, res, 2)
+    y, upd = M.upscaler_attention_forward(leaf, torch.tensor(x, dtype=torch.float64), True, res, factor)
     loss = ((y - torch.tensor(t, dtype=torch.float64)) ** 2).mean()
     names = [n_ for n_, v in leaf.items() if v.requires_grad]
     grads = dict(zip(names, torch.autograd.grad(loss, [leaf[n_] for n_ in names])))
     leaf32 = M.to_torch(gw, torch.float32, requires_grad=True)
-    y32, _ = M.upscaler_attention_forward(leaf32, torch.tensor(x), True, res, 2)
+    y32, _ = M.upscaler_attention_forward(leaf32, torch.tensor(x), True, res, factor)
     g32 = dict(zip(names, torch.autograd.grad(((y32 - torch.tensor(t)) ** 2).mean(), [leaf32[n_] for n_ in names])))
     yd, tape = G.forward(E.to_device_nchw(rt, x), True)
     e1 = rel_err(E.to_nhwc(rt, yd), y)
@@ -143,7 +145,7 @@ def test_upscaler_attention_matches_oracle(rt):
     sw = G.get_weights_dict()
     for n_, v in upd.items():
         assert np.max(np.abs(sw[n_] - v.detach().numpy())) < 1e-4 * (np.max(np.abs(v.detach().numpy())) + 1e-3), n_
-    report("make_upscaler_attention: predict err=%.2e train fwd err=%.2e worst gradient err=%.2e" % (e0, e1, worst))
+    report("make_upscaler_attention x%d: predict err=%.2e train fwd err=%.2e worst gradient err=%.2e" % (factor, e0, e1, worst))
     assert e0 < 1e-3 and e1 < 1e-3
 
 

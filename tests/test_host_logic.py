@@ -83,6 +83,17 @@ def test_reference_signatures_are_mirrored():
     assert params(PM.make_discriminator_sparse_512)[:2] == [("input_shape", inspect._empty), ("activation", "none")]
     assert params(PM.make_upscaler_attention)[:5] == [("output_image_shape", inspect._empty), ("kernel_size", 5), ("filters", 64),
                                                       ("upscale_factor", 4), ("res_block_num", 16)]
+    # the other -gm choices: :332, :570, :642, :743 and their blocks :505-566
+    assert params(PM.make_upscaler_skip_con)[:4] == [("output_image_shape", inspect._empty), ("kernel_size", 5), ("filters", 64), ("upscale_factor", 4)]
+    assert params(PM.make_upscaler_unetish)[:7] == [("output_image_shape", inspect._empty), ("kernel_size", 5), ("upscale_factor", 4), ("step_size", 4),
+                                                    ("downscale_times", 5), ("initial_step_filter_count", 32), ("dropout_rate", 0.1)]
+    assert params(PM.make_upscaler_unetish_add)[:7] == [("output_image_shape", inspect._empty), ("kernel_size", 5), ("upscale_factor", 4), ("step_size", 4),
+                                                        ("downscale_times", 5), ("initial_step_filter_count", 48), ("dropout_rate", 0.1)]
+    assert params(PM.make_upscaler_unetish_complex)[:7] == [("output_image_shape", inspect._empty), ("kernel_size", 5), ("upscale_factor", 4),
+                                                            ("step_size", 4), ("downscale_times", 3), ("initial_step_filter_count", 32), ("dropout_rate", 0.1)]
+    for f in (PM.same_size_unetish_block, PM.downsampling_unetish_block, PM.upsampling_unetish_block):
+        assert params(f) == [("model", inspect._empty), ("kernel_size", inspect._empty), ("filters", inspect._empty), ("strides", inspect._empty),
+                             ("name", inspect._empty), ("dropout_rate", 0.1)]
     # the block functions, :30 and :78
     assert [n for n, _ in params(PM.residual_block_attention)][:6] == ["model", "input_", "kernel_size", "filters", "strides", "batch_norm"]
     assert [n for n, _ in params(PM.upsampling_block_attention)][:5] == ["model", "input_", "scale", "kernel_size", "filters"]

@@ -384,3 +384,66 @@ def test_gan_loss_all_activation_pairs(rt, head, loss_act):
     out2 = rt.zeros(1)
     E.gan_loss(rt, means2[0:1], means2[1:2], 0.5, lk, out2, da, 1.0 / 6, db, -1.0 / 6)
     assert torch.equal(out2, out)
+
+
+# ---- resize / crop / pad / channel copies / dropout (generators behind train_gan3.py -gm: model.py:332-363, 505-827) ----------------
+@pytest.mark.parametrize("factor", [2, 3, 4])
+@pytest.mark.parametrize("mode", ["nearest", "bilinear"])
+def test_resize2d_is_tf1_resize_images(rt, factor, mode):
+    from oracle import models as M
+    from upscaler import _lib as L
+    x = torch.randn(2, 3, 13, 17)
+    xd = x.to(rt.device)
+    y = rt.empty(2, 3, 13 * factor, 17 * factor)
+    L.check(rt.lib.vcg_resize2d(xd.data_ptr(), y.data_ptr(), 6, 13, 17, factor, 1 if mode == "bilinear" else 0, rt.stream), "vcg_resize2d")
+    ref = M.resize_images_tf1(x.double(), factor, mode)
+    if mode == "nearest":
+        assert torch.equal(y.cpu().double(), ref)
+    else:
+        # the kernel forms the source coordinate as TF does, y * (in / (float)out) in fp32: exact for the power-of-two factors the
+        # reference uses, one fp32 rounding of the lerp weight (times the coordinate) for factor 3
+        assert float((y.cpu().double() - ref).abs().max()) < (2e-6 if factor != 3 else 1e-5)
+
+
+def test_crop_pad_and_channel_copies(rt):
+    from upscaler import _lib as L
+    x = torch.randn(3, 5, 11, 14).to(rt.device)
+    y = rt.empty(3, 5, 8, 9)
+    L.check(rt.lib.vcg_crop2d(x.data_ptr(), y.data_ptr(), 15, 11, 14, 1, 3, 8, 9, rt.stream), "vcg_crop2d")
+    assert torch.equal(y, x[:, :, 1:9, 3:12])
+    back = rt.empty(3, 5, 11, 14)
+    L.check(rt.lib.vcg_pad2d(y.data_ptr(), back.data_ptr(), 15, 8, 9, 1, 3, 11, 14, rt.stream), "vcg_pad2d")
+    ref = torch.zeros_like(x)
+    ref[:, :, 1:9, 3:12] = x[:, :, 1:9, 3:12]
+    assert torch.equal(back, ref)
+    assert rt.lib.vcg_crop2d(x.data_ptr(), y.data_ptr(), 15, 11, 14, 4, 3, 8, 9, rt.stream) == -2       # VCG_E_SHAPE: the window leaves the source
+    a, b = torch.randn(2, 3, 6, 7).to(rt.device), torch.randn(2, 224, 6, 7).to(rt.device)
+    cat = rt.empty(2, 227, 6, 7)
+    L.check(rt.lib.vcg_copy_channels(a.data_ptr(), cat.data_ptr(), 2, 3, 0, 227, 0, 3, 42, rt.stream), "copy a")
+    L.check(rt.lib.vcg_copy_channels(b.data_ptr(), cat.data_ptr(), 2, 224, 0, 227, 3, 224, 42, rt.stream), "copy b")
+    assert torch.equal(cat, torch.cat([a, b], 1))
+    part = rt.empty(2, 100, 6, 7)
+    L.check(rt.lib.vcg_copy_channels(cat.data_ptr(), part.data_ptr(), 2, 227, 50, 100, 0, 100, 42, rt.stream), "slice")
+    assert torch.equal(part, cat[:, 50:150])
+
+
+def test_dropout_is_tf_nn_dropout_given_the_mask(rt):
+    from upscaler import _lib as L
+    n = 1 << 20
+    x = torch.randn(n).to(rt.device)
+    step = torch.zeros(1, dtype=torch.int64, device=rt.device)
+    outs = []
+    for it in range(2):
+        y, mask = rt.empty(n), torch.empty(n, dtype=torch.uint8, device=rt.device)
+        L.check(rt.lib.vcg_dropout_fwd(x.data_ptr(), y.data_ptr(), mask.data_ptr(), n, 0.1, 1234, step.data_ptr(), rt.stream), "vcg_dropout_fwd")
+        keep = torch.tensor(0.9, dtype=torch.float32, device=rt.device)          # tf.nn.dropout: div(x, keep_prob) * mask, a true division
+        assert torch.equal(y, torch.where(mask.bool(), torch.div(x, keep), torch.zeros_like(x)))
+        assert abs(float(mask.float().mean()) - 0.9) < 2e-3                   # keep probability 1 - rate (sigma = 3e-4)
+        dy, dx = torch.randn(n).to(rt.device), rt.empty(n)
+        L.check(rt.lib.vcg_dropout_bwd(dy.data_ptr(), mask.data_ptr(), dx.data_ptr(), n, 0.1, rt.stream), "vcg_dropout_bwd")
+        assert torch.equal(dx, torch.where(mask.bool(), torch.div(dy, keep), torch.zeros_like(dy)))
+        outs.append(mask.clone())
+        L.check(rt.lib.vcg_counter_inc(step.data_ptr(), rt.stream), "vcg_counter_inc")
+    assert int(step.item()) == 2
+    both = float((outs[0] & outs[1]).float().mean())
+    assert abs(both - 0.81) < 3e-3                                            # the two steps' masks are independent

@@ -1,7 +1,10 @@
 """Pins the oracle against every known answer the reference's own notebooks hold for this path
  -- shapes, parameter counts, value map.  The reference has no numeric golden
 vectors ("parity unpinned"), so these are the only reference-derived pins."""
+import math
+
 import numpy as np
+import pytest
 import torch
 
 from oracle import data as OD
@@ -141,3 +144,78 @@ def test_sparse_512_and_attention_generator_sizes():
     expect = conv(9, c, f) + f + res * (conv(k, c, f) + 2 * conv(k, f, f) + 2 * bn + f) + conv(k, f, f) + bn \
         + conv(k, 2 * c, f) + conv(k, f, 128) + conv(3, c, 128) + conv(9, 128, 3)
     assert M.count_params(gw) == expect
+
+
+# ---- the other generators behind train_gan3.py -gm (oracle/generators.py) ---------------------------------------------------------
+def test_skip_con_parameter_count_and_the_reference_name_clash():
+    """make_upscaler_skip_con (model.py:332-363) at its defaults, counted by hand: 9x9 3->64 conv 15 616 + PReLU 64; 16 residual blocks of
+    2 x (5*5*64*64 + 64) + 2 x 256 (BN: gamma, beta, moving mean / variance) + 64 = 205 504; 3x3 conv 36 928 + BN 256; Conv2DTranspose 3x3
+    64->224 129 248 and 224->224 451 808; 9x9 conv (3 + 224)->3 55 164.  As written the reference cannot build it: sixteen layers named
+    '/conv_pre' (keras.engine.network refuses duplicate names); the restatement raises the same way."""
+    from oracle import generators as G, models as M
+    with pytest.raises(ValueError, match="unique"):
+        G.init_weights(G.upscaler_skip_con, (8, 8, 3), 1)
+    w = G.init_weights(G.upscaler_skip_con, (8, 8, 3), 1, unique_names=True)
+    assert M.count_params(w) == 15616 + 64 + 16 * 205504 + 36928 + 256 + 129248 + 451808 + 55164 == 3977148
+    assert w["conv2d_3/kernel"].shape == (9, 9, 227, 3)                 # Keras' automatic names, counted per class from 1
+    assert "batch_normalization_1/gamma" in w and "p_re_lu_1/alpha" in w
+
+
+def _unetish_count(k, factor, step, down, c0, concat, halve):
+    """independent arithmetic over model.py:577-609: (cin, cout) of every Conv2D / Conv2DTranspose + BN (4c) + PReLU (c) of the U"""
+    total = 81 * 3 * c0 + c0 + c0
+    blk = lambda ci, co: k * k * ci * co + co + 4 * co + co
+    c, skips = c0, []
+    cur = c0
+    for _ in range(down):
+        for _ in range(step):
+            total += blk(cur, c); cur = c
+        skips.append(cur)
+        total += blk(cur, c); cur = c
+        c *= 2
+    for _ in range(step):
+        total += blk(cur, c); cur = c
+    if halve:
+        c //= 2
+    ups = int(math.log2(factor)) + down
+    for s_ in range(ups):
+        total += blk(cur, c); cur = c
+        if s_ < len(skips):
+            cur = cur + skips[len(skips) - s_ - 1] if concat else cur
+            c //= 2
+        for _ in range(step):
+            total += blk(cur, c); cur = c
+    return total, cur
+
+
+def test_unetish_parameter_counts_and_shapes():
+    from oracle import generators as G, models as M
+    # reference defaults (kernel 5, x4, step size 4, five / five / three down-samplings)
+    w = G.init_weights(G.upscaler_unetish, (32, 32, 3), 1)
+    body, cl = _unetish_count(5, 4, 4, 5, 32, True, False)
+    assert M.count_params(w) == body + 81 * cl * 3 + 3
+    w = G.init_weights(G.upscaler_unetish_add, (32, 32, 3), 1)
+    body, cl = _unetish_count(5, 4, 4, 5, 48, False, True)
+    assert M.count_params(w) == body + (81 * cl * 3 + 3) + (81 * 3 * 3 + 3)
+    w = G.init_weights(G.upscaler_unetish_complex, (32, 32, 3), 1)
+    body, cl = _unetish_count(5, 4, 4, 3, 32, True, False)
+    head = (81 * 3 * 3 + 3) + (81 * 6 * 3 + 3) * 3 + (81 * cl * 3 + 3) + 2 * (81 * 3 * 3 + 3) + 3 * (81 * 6 * 3 + 3)
+    assert M.count_params(w) == body + head
+    # an odd frame: 11 -> 6 -> 12 is cropped back to 11 at the join, the output is exactly factor x input
+    x = torch.rand(1, 22, 30, 3, dtype=torch.float64)
+    kw = dict(kernel_size=3, upscale_factor=2, step_size=1, downscale_times=2, initial_step_filter_count=8)
+    for fn in (G.upscaler_unetish, G.upscaler_unetish_add, G.upscaler_unetish_complex):
+        wf = G.init_weights(fn, (22, 30, 3), 2, **kw)
+        with torch.no_grad():
+            y = fn(G.Net(M.to_torch(wf, torch.float64), False), x, **kw)
+        assert y.shape == (1, 44, 60, 3) and float(y.abs().max()) <= 1.0
+
+
+def test_dropout_restatement_is_identity_outside_training_and_scales_inside():
+    from oracle import generators as G
+    x = torch.arange(12, dtype=torch.float64).view(1, 3, 2, 2)
+    mask = (torch.arange(12).view(1, 3, 2, 2) % 3 != 0)
+    assert torch.equal(G.Net({}, False).dropout(x, 0.25, "d"), x)                       # learning phase 0
+    assert torch.equal(G.Net({}, True).dropout(x, 0.0, "d"), x)                         # keras.layers.Dropout.call: 0 < rate < 1
+    y = G.Net({}, True, masks={"d": mask}).dropout(x, 0.25, "d")
+    assert torch.equal(y, torch.where(mask, x / 0.75, torch.zeros_like(x)))

@@ -377,6 +377,79 @@ __global__ void dilate2d_kernel(const float* __restrict__ src, float* __restrict
     dst[i] = (x % s == 0 && y % s == 0) ? src[(pl * h + y / s) * w + x / s] : 0.f;
 }
 
+// K.resize_images on TF 1.14: source coordinate = destination / f (align_corners=False, no half-pixel centres)
+__global__ void resize2d_kernel(const float* __restrict__ src, float* __restrict__ dst, size_t planes, int h, int w, int f, int bilinear) {
+    const int oh = h * f, ow = w * f;
+    const size_t total = planes * oh * ow;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int x = (int)(i % ow), y = (int)((i / ow) % oh);
+    const float* s = src + (i / ((size_t)ow * oh)) * h * w;
+    const int y0 = y / f, x0 = x / f;
+    if (!bilinear) {
+        dst[i] = s[y0 * w + x0];
+        return;
+    }
+    // the fractions j/f are formed as TF forms them: in_y = y * (h / (float)oh), lerp weight = in_y - floor(in_y)
+    const float sc = 1.0f / (float)f;
+    const float fy = (float)y * sc - (float)y0, fx = (float)x * sc - (float)x0;
+    const int y1 = min(y0 + 1, h - 1), x1 = min(x0 + 1, w - 1);
+    const float tl = s[y0 * w + x0], tr = s[y0 * w + x1], bl = s[y1 * w + x0], br = s[y1 * w + x1];
+    const float top = tl + (tr - tl) * fx, bot = bl + (br - bl) * fx;
+    dst[i] = top + (bot - top) * fy;
+}
+
+// dst (oh x ow) = window of src (h x w) at (top, left); PAD: the reverse (src placed into a zeroed dst)
+template <bool PAD>
+__global__ void crop_pad2d_kernel(const float* __restrict__ src, float* __restrict__ dst, size_t planes, int h, int w, int top, int left,
+                                  int oh, int ow) {
+    const size_t total = planes * oh * ow;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int x = (int)(i % ow), y = (int)((i / ow) % oh);
+    const size_t pl = i / ((size_t)ow * oh);
+    if (PAD) {
+        const int sy = y - top, sx = x - left;
+        dst[i] = ((unsigned)sy < (unsigned)h && (unsigned)sx < (unsigned)w) ? src[(pl * h + sy) * w + sx] : 0.f;
+    } else {
+        dst[i] = src[(pl * h + y + top) * w + x + left];
+    }
+}
+
+__global__ void copy_channels_kernel(const float* __restrict__ src, float* __restrict__ dst, int c_src, int c_src_off, int c_dst, int c_dst_off,
+                                     int c_count, size_t hw, size_t total) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const size_t p = i % hw, c = (i / hw) % c_count, n = i / (hw * c_count);
+    dst[(n * c_dst + c_dst_off + c) * hw + p] = src[(n * c_src + c_src_off + c) * hw + p];
+}
+
+// counter-based uniform in [0, 1): two rounds of the splitmix64 finaliser over (seed, step, index)
+__device__ __forceinline__ float hash_uniform(unsigned long long seed, unsigned long long step, unsigned long long idx) {
+    unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (step + 1) + 0xD1B54A32D192ED03ull * idx;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return (float)(unsigned)(z >> 40) * (1.0f / 16777216.0f);
+}
+
+__global__ void dropout_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, unsigned char* __restrict__ mask, size_t count, float rate,
+                                   unsigned long long seed, const unsigned long long* __restrict__ step) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= count) return;
+    const bool keep = hash_uniform(seed, step ? *step : 0ull, i) >= rate;
+    mask[i] = keep ? 1 : 0;
+    y[i] = keep ? x[i] / (1.0f - rate) : 0.f;
+}
+
+__global__ void dropout_bwd_kernel(const float* __restrict__ dy, const unsigned char* __restrict__ mask, float* __restrict__ dx, size_t count, float rate) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= count) return;
+    dx[i] = mask[i] ? dy[i] / (1.0f - rate) : 0.f;
+}
+
+__global__ void counter_inc_kernel(unsigned long long* c) { *c += 1; }
+
 inline unsigned blocks_for(size_t count) { return (unsigned)((count + 255) / 256); }
 
 }  // namespace
@@ -535,6 +608,71 @@ int vcg_dilate2d(const float* src, float* dst, size_t planes, int h, int w, int 
     if (planes == 0 || h <= 0 || w <= 0 || stride < 1) return VCG_E_SHAPE;
     const size_t total = planes * ((size_t)(h - 1) * stride + 1) * ((size_t)(w - 1) * stride + 1);
     hipLaunchKernelGGL(dilate2d_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, src, dst, planes, h, w, stride);
+    VCG_LAUNCH_CHECK();
+    return VCG_OK;
+}
+
+int vcg_resize2d(const float* src, float* dst, size_t planes, int h, int w, int factor, int bilinear, vcg_stream_t stream) {
+    VCG_CHECK_PTR(src); VCG_CHECK_PTR(dst);
+    if (planes == 0 || h <= 0 || w <= 0 || factor < 1) return VCG_E_SHAPE;
+    const size_t total = planes * (size_t)h * factor * w * factor;
+    hipLaunchKernelGGL(resize2d_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, src, dst, planes, h, w, factor, bilinear);
+    VCG_LAUNCH_CHECK();
+    return VCG_OK;
+}
+
+int vcg_crop2d(const float* src, float* dst, size_t planes, int h, int w, int top, int left, int oh, int ow, vcg_stream_t stream) {
+    VCG_CHECK_PTR(src); VCG_CHECK_PTR(dst);
+    if (planes == 0 || h <= 0 || w <= 0 || oh <= 0 || ow <= 0 || top < 0 || left < 0 || top + oh > h || left + ow > w) return VCG_E_SHAPE;
+    hipLaunchKernelGGL(crop_pad2d_kernel<false>, dim3(blocks_for(planes * oh * ow)), dim3(256), 0, (hipStream_t)stream, src, dst, planes, h, w, top,
+                       left, oh, ow);
+    VCG_LAUNCH_CHECK();
+    return VCG_OK;
+}
+
+int vcg_pad2d(const float* src, float* dst, size_t planes, int h, int w, int top, int left, int oh, int ow, vcg_stream_t stream) {
+    VCG_CHECK_PTR(src); VCG_CHECK_PTR(dst);
+    if (planes == 0 || h <= 0 || w <= 0 || oh <= 0 || ow <= 0 || top < 0 || left < 0 || top + h > oh || left + w > ow) return VCG_E_SHAPE;
+    hipLaunchKernelGGL(crop_pad2d_kernel<true>, dim3(blocks_for(planes * oh * ow)), dim3(256), 0, (hipStream_t)stream, src, dst, planes, h, w, top,
+                       left, oh, ow);
+    VCG_LAUNCH_CHECK();
+    return VCG_OK;
+}
+
+int vcg_copy_channels(const float* src, float* dst, int n, int c_src, int c_src_off, int c_dst, int c_dst_off, int c_count, size_t hw,
+                      vcg_stream_t stream) {
+    VCG_CHECK_PTR(src); VCG_CHECK_PTR(dst);
+    if (n <= 0 || c_count <= 0 || hw == 0 || c_src_off < 0 || c_dst_off < 0 || c_src_off + c_count > c_src || c_dst_off + c_count > c_dst)
+        return VCG_E_SHAPE;
+    const size_t total = (size_t)n * c_count * hw;
+    hipLaunchKernelGGL(copy_channels_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, src, dst, c_src, c_src_off, c_dst, c_dst_off,
+                       c_count, hw, total);
+    VCG_LAUNCH_CHECK();
+    return VCG_OK;
+}
+
+int vcg_dropout_fwd(const float* x, float* y, unsigned char* mask, size_t count, float rate, unsigned long long seed,
+                    const unsigned long long* step, vcg_stream_t stream) {
+    VCG_CHECK_PTR(x); VCG_CHECK_PTR(y); VCG_CHECK_PTR(mask);
+    if (!(rate >= 0.f && rate < 1.f)) return VCG_E_SHAPE;
+    if (count == 0) return VCG_OK;
+    hipLaunchKernelGGL(dropout_fwd_kernel, dim3(blocks_for(count)), dim3(256), 0, (hipStream_t)stream, x, y, mask, count, rate, seed, step);
+    VCG_LAUNCH_CHECK();
+    return VCG_OK;
+}
+
+int vcg_dropout_bwd(const float* dy, const unsigned char* mask, float* dx, size_t count, float rate, vcg_stream_t stream) {
+    VCG_CHECK_PTR(dy); VCG_CHECK_PTR(mask); VCG_CHECK_PTR(dx);
+    if (!(rate >= 0.f && rate < 1.f)) return VCG_E_SHAPE;
+    if (count == 0) return VCG_OK;
+    hipLaunchKernelGGL(dropout_bwd_kernel, dim3(blocks_for(count)), dim3(256), 0, (hipStream_t)stream, dy, mask, dx, count, rate);
+    VCG_LAUNCH_CHECK();
+    return VCG_OK;
+}
+
+int vcg_counter_inc(unsigned long long* counter, vcg_stream_t stream) {
+    VCG_CHECK_PTR(counter);
+    hipLaunchKernelGGL(counter_inc_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, counter);
     VCG_LAUNCH_CHECK();
     return VCG_OK;
 }

@@ -367,6 +367,69 @@ class ConvT2D(Layer):
         return dx
 
 
+class ConvTDilated(ConvT2D):
+    """keras.layers.Conv2DTranspose(strides=s, padding='same') for any stride, as the data gradient of the stride-1 convolution its
+    Keras kernel (kh, kw, out, in) is the HWIO kernel of, evaluated over the zero-dilated input: the ``to_add_input`` branch of the x4
+    attention generator (kernel 5, strides 4, model.py:95).  That branch transposes a function of the network INPUT, so only the
+    forward pass and the parameter gradients exist here; asking for the input gradient raises."""
+
+    def __init__(self, name, cin, cout, k, stride):
+        super().__init__(name, cin, cout, k, L.ACT_NONE, 0.0)
+        if k < stride:
+            raise NotImplementedError("Conv2DTranspose with kernel_size < strides")
+        self.stride = stride
+        self._ones = None
+
+    def _descs(self, n, h, w):
+        s, k = self.stride, self.k
+        hd, wd = (h - 1) * s + 1, (w - 1) * s + 1
+        crop = (k - s) // 2                                   # 'same': the full transposed convolution, cropped crop / k - s - crop
+        # the virtual convolution: [cout, h*s, w*s] -> [cin, hd, wd], stride 1, pads (crop, crop)
+        return hd, wd, L.ConvDesc(n, self.cout, h * s, w * s, self.cin, hd, wd, k, k, 1, crop, crop)
+
+    def _wt(self):
+        rt = self.rt
+        if self.wt is None:
+            self.wt = rt.empty(self.k * self.k, self.cin, self.cout)
+        if not self._wt_valid:
+            L.check(rt.lib.vcg_kernel_transpose(self.ps[self.name + "/kernel"].data_ptr(), self.wt.data_ptr(), self.k * self.k, self.cout, self.cin,
+                                                rt.stream), "vcg_kernel_transpose")
+            self._wt_valid = True
+        return self.wt
+
+    def forward(self, x, tag=None):
+        rt = self.rt
+        n, _, h, w = x.shape
+        hd, wd, d = self._descs(n, h, w)
+        xd = rt.empty(n, self.cin, hd, wd)
+        L.check(rt.lib.vcg_dilate2d(x.data_ptr(), xd.data_ptr(), n * self.cin, h, w, self.stride, rt.stream), "vcg_dilate2d")
+        z = rt.empty(n, self.cout, d.h, d.w)
+        L.check(rt.lib.vcg_conv2d_dgrad(ctypes.byref(d), xd.data_ptr(), self.ps[self.name + "/kernel"].data_ptr(), self._wt().data_ptr(), z.data_ptr(),
+                                        None, rt.stream), "vcg_conv2d_dgrad[%s]" % self.name)
+        if self._ones is None:
+            self._ones = filled_like(rt, self.ps[self.name + "/bias"], 1.0)
+        y = rt.empty(*z.shape)                                 # + bias: y = 1 * z + bias[c]
+        L.check(rt.lib.vcg_norm_act_fwd(z.data_ptr(), n, self.cout, d.h * d.w, self._ones.data_ptr(), self.ps[self.name + "/bias"].data_ptr(), 0,
+                                        L.ACT_NONE, 0.0, None, None, y.data_ptr(), rt.stream), "vcg_norm_act_fwd[%s]" % self.name)
+        return y, (xd, d)
+
+    def backward(self, ctx, dy, need_dx=True, param_grads=True, which=0, tag=None):
+        rt = self.rt
+        xd, d = ctx
+        if need_dx:
+            raise NotImplementedError("Conv2DTranspose(strides=%d): the input gradient is not built (the reference applies it to the network input)"
+                                      % self.stride)
+        if param_grads:
+            ws, wsn = rt.workspace(max(rt.lib.vcg_conv2d_wgrad_workspace_bytes(ctypes.byref(d)),
+                                       rt.lib.vcg_channel_sum_workspace_bytes(d.n, self.cout, d.h * d.w)))
+            # dL/dW[tap][out][in] = sum dy[out][i + tap - crop] * xd[in][i]: the weight gradient of the virtual convolution with x := dy, dy := xd
+            L.check(rt.lib.vcg_conv2d_wgrad(ctypes.byref(d), dy.data_ptr(), xd.data_ptr(), self.ps.grad(self.name + "/kernel", which).data_ptr(), None,
+                                            ws, wsn, rt.stream), "vcg_conv2d_wgrad[%s]" % self.name)
+            L.check(rt.lib.vcg_channel_sum(dy.data_ptr(), d.n, self.cout, d.h * d.w, self.ps.grad(self.name + "/bias", which).data_ptr(), ws, wsn,
+                                           rt.stream), "vcg_channel_sum[%s]" % self.name)
+        return None
+
+
 class NormAct(Layer):
     """[BatchNormalization | instance norm | identity] -> [PReLU | LeakyReLU | none] -> [+ residual].
 

@@ -29,29 +29,56 @@ class _Graph:
     def __init__(self, input_shape):
         self.input_shape = tuple(input_shape)
         self.nodes = []          # (kind, layer, input nids, attrs)
+        self.hw = []             # static (h, w) of every node, as Keras infers it (the reference reads it through Model(...).output_shape)
         self.names = set()
+        self.uids = {}           # Keras' per-class counters behind the names of unnamed layers (conv2d_1, batch_normalization_2, p_re_lu_1 ...)
+
+    def auto_name(self, cls):
+        self.uids[cls] = self.uids.get(cls, 0) + 1
+        return "%s_%d" % (cls, self.uids[cls])
 
     def add(self, kind, layer, inputs, **attrs):
-        if layer is not None:
-            if layer.name in self.names:
-                raise ValueError("duplicate layer name %r" % layer.name)
-            self.names.add(layer.name)
-        attrs.pop("name", None)
+        lname = layer.name if layer is not None else attrs.get("name")
+        if lname is not None:
+            if lname in self.names:
+                # keras.engine.network: 'The name "..." is used N times in the model. All layer names should be unique.'
+                raise ValueError("duplicate layer name %r: all layer names should be unique" % lname)
+            self.names.add(lname)
         self.nodes.append([kind, layer, list(inputs), attrs])
+        self.hw.append(self._infer_hw(kind, layer, list(inputs), attrs))
         return len(self.nodes) - 1
+
+    def _infer_hw(self, kind, layer, ins, attrs):
+        if kind == "input":
+            return (self.input_shape[0], self.input_shape[1])
+        h, w = self.hw[ins[0]]
+        if kind == "conv":
+            oh, ow, _, _ = layer.out_hw(h, w)
+            return (oh, ow)
+        if kind == "convt":
+            return (attrs.get("stride", 2) * h, attrs.get("stride", 2) * w)
+        if kind == "resize":
+            return (h * attrs["factor"], w * attrs["factor"])
+        if kind == "crop":
+            (t, b), (l, r) = attrs["cropping"]
+            return (h - t - b, w - l - r)
+        if kind == "gate":
+            return self.hw[ins[1]]
+        for j in ins[1:]:
+            if self.hw[j] != (h, w) and kind in ("norm", "concat"):
+                raise ValueError("%s of tensors with different sizes %s / %s" % (kind, (h, w), self.hw[j]))
+        return (h, w)
 
     def consumers(self, nid):
         return [i for i, n in enumerate(self.nodes) if nid in n[2]]
 
 
-_auto = [0]
-
-
-def _name(name, default):
+def _name(name, default, model=None):
+    """an explicit name, or Keras' automatic one (per-class counter, here scoped to the graph)"""
     if name:
         return name
-    _auto[0] += 1
-    return "%s_%d" % (default, _auto[0])
+    g = model.graph if isinstance(model, KTensor) else model
+    return g.auto_name(default)
 
 
 def Input(shape, name=None):
@@ -71,24 +98,31 @@ def conv2d(model, filters, kernel_size, strides=1, padding="same", activation=No
         act, alpha = L.ACT_LRELU, float(activation[1])
     elif activation is not None:
         raise ValueError("unsupported activation %r" % (activation,))
-    layer = E.Conv2D(_name(name, "conv2d"), model.channels, filters, kernel_size, strides, padding, act, alpha)
+    layer = E.Conv2D(_name(name, "conv2d", model), model.channels, filters, kernel_size, strides, padding, act, alpha)
     return KTensor(model.graph, model.graph.add("conv", layer, [model.nid]), filters)
 
 
 def batch_norm(model, name=None, norm="batch"):
-    layer = E.NormAct(_name(name, "batch_norm"), model.channels, norm)
+    layer = E.NormAct(_name(name, "batch_normalization", model), model.channels, norm)
+    return KTensor(model.graph, model.graph.add("norm", layer, [model.nid]), model.channels)
+
+
+def batch_norm_prelu(model, name=None, prelu_name=None, norm="batch"):
+    """BatchNormalization() followed by PReLU(shared_axes=[1,2]) as one fused node (model.py:508-509,517-518,526-527)"""
+    n = _name(name, "batch_normalization", model)
+    layer = E.NormAct(n, model.channels, norm, L.ACT_PRELU, prelu_name=_name(prelu_name, "p_re_lu", model))
     return KTensor(model.graph, model.graph.add("norm", layer, [model.nid]), model.channels)
 
 
 def prelu(model, name=None):
     """PReLU(alpha_initializer='zeros', shared_axes=[1,2]) (model.py:21,276)"""
-    n = _name(name, "prelu")
+    n = _name(name, "p_re_lu", model)
     layer = E.NormAct(n + "_op", model.channels, None, L.ACT_PRELU, prelu_name=n)
     return KTensor(model.graph, model.graph.add("norm", layer, [model.nid]), model.channels)
 
 
 def leaky_relu(model, alpha, name=None):
-    layer = E.NormAct(_name(name, "leaky_relu"), model.channels, None, L.ACT_LRELU, alpha)
+    layer = E.NormAct(_name(name, "leaky_re_lu", model), model.channels, None, L.ACT_LRELU, alpha)
     return KTensor(model.graph, model.graph.add("norm", layer, [model.nid]), model.channels)
 
 
@@ -103,9 +137,13 @@ def add(tensors, name=None):
         node = g.nodes[y.nid]
         if node[0] == "norm" and len(node[2]) == 1 and not g.consumers(y.nid) and node[1].act == L.ACT_NONE \
                 and y.nid == len(g.nodes) - 1:
+            if g.hw[x.nid] != g.hw[y.nid] or x.channels != y.channels:
+                raise ValueError("Add of tensors with different shapes")
             node[2].append(x.nid)            # second input = residual
             return KTensor(g, y.nid, y.channels)
-    layer = E.NormAct(_name(name, "add"), a.channels, None)
+    if a.channels != b.channels:
+        raise ValueError("Add of tensors with %d and %d channels" % (a.channels, b.channels))
+    layer = E.NormAct(_name(name, "add", g), a.channels, None)
     return KTensor(g, g.add("norm", layer, [b.nid, a.nid]), a.channels)
 
 
@@ -114,41 +152,78 @@ def multiply_sigmoid(attention, model, name=None):
     g = model.graph
     if attention.graph is not g or attention.channels != model.channels:
         raise ValueError("attention and model must belong to one graph and have equal channel counts")
-    return KTensor(g, g.add("gate", None, [attention.nid, model.nid], name=_name(name, "attention_multiply")), model.channels)
+    return KTensor(g, g.add("gate", None, [attention.nid, model.nid], name=_name(name, "multiply", g)), model.channels)
 
 
 def concatenate(tensors, name=None):
     """Concatenate(axis=3) of NHWC tensors = channel concatenation"""
     g = tensors[0].graph
-    return KTensor(g, g.add("concat", None, [t.nid for t in tensors], name=_name(name, "concat")), sum(t.channels for t in tensors))
+    return KTensor(g, g.add("concat", None, [t.nid for t in tensors], name=_name(name, "concatenate", g)), sum(t.channels for t in tensors))
 
 
 def resize_images(model, factor, interpolation="nearest", name=None):
-    """Lambda(K.resize_images(x, f, f, 'channels_last', interpolation)) (model.py:80-81).  Only factor 1 -- the identity, which is
-    what the up-sampling attention block of an x2 generator asks for (scale // 2 with scale = 2) -- is instantiated."""
-    if factor != 1:
-        raise NotImplementedError("resize_images is instantiated for factor 1 (upscale_factor=2 generators)")
+    """Lambda(K.resize_images(x, f, f, 'channels_last', interpolation)) (model.py:80-81,352,705,786): tf.image.resize_* with
+    align_corners=False.  Forward only -- the reference resizes nothing but the network input, which is data; factor 1 is the identity."""
     if interpolation not in ("nearest", "bilinear"):
         raise ValueError(interpolation)
-    return model
+    if factor == 1:
+        return model
+    if factor < 1 or int(factor) != factor:
+        raise ValueError("resize factor %r" % (factor,))
+    g = model.graph
+    return KTensor(g, g.add("resize", None, [model.nid], factor=int(factor), bilinear=interpolation == "bilinear", name=_name(name, "lambda", g)),
+                   model.channels)
+
+
+def cropping2d(model, cropping, name=None):
+    """Cropping2D(cropping=((top, bottom), (left, right))) (model.py:552,563,626)"""
+    (t, b), (l, r) = cropping
+    if min(t, b, l, r) < 0:
+        raise ValueError("negative cropping %r" % (cropping,))
+    g = model.graph
+    if t == b == l == r == 0:
+        g.names.add(_name(name, "cropping2d", g))         # the layer exists in Keras (its name is taken); it moves no data
+        return model
+    return KTensor(g, g.add("crop", None, [model.nid], cropping=((t, b), (l, r)), name=_name(name, "cropping2d", g)), model.channels)
+
+
+def dropout(model, rate, name=None):
+    """Dropout(rate) (model.py:510,519,528): identity at inference and for rates outside (0, 1) (keras.layers.Dropout.call); in the
+    learning phase x * mask / (1 - rate) with a fresh mask per step (device-side counter, so a recorded hipGraph redraws it)."""
+    g = model.graph
+    n = _name(name, "dropout", g)
+    return KTensor(g, g.add("dropout", None, [model.nid], rate=float(rate), name=n), model.channels)
+
+
+def activation(model, kind, name=None):
+    """Activation('sigmoid' | 'tanh') as a layer of its own (model.py:799): y = act(x)"""
+    if kind not in ("sigmoid", "tanh"):
+        raise ValueError("unsupported activation %r" % (kind,))
+    g = model.graph
+    return KTensor(g, g.add("act", None, [model.nid], head=L.HEAD_KINDS[kind], name=_name(name, "activation", g)), model.channels)
 
 
 def atanh_scaled(model, scale=0.99999, name=None):
     """Lambda(lambda x: tf.math.atanh(0.99999 * x)) (model.py:94); defined on data tensors (no gradient)"""
     g = model.graph
-    return KTensor(g, g.add("atanh", None, [model.nid], scale=float(scale), name=_name(name, "atanh")), model.channels)
+    return KTensor(g, g.add("atanh", None, [model.nid], scale=float(scale), name=_name(name, "lambda", g)), model.channels)
 
 
 def conv2d_transpose(model, filters, kernel_size, strides=2, activation=None, name=None):
-    """Conv2DTranspose(filters, kernel_size, strides=2, padding='same') [+ fused LeakyReLU when activation = ('lrelu', alpha)]"""
+    """Conv2DTranspose(filters, kernel_size, strides, padding='same') [+ fused LeakyReLU when activation = ('lrelu', alpha)].  Strides
+    other than 2 (the x4 attention generator's strides-4 transpose of the input, model.py:95) run as a stride-1 data gradient over the
+    zero-dilated tensor and are built for tensors derived from the network input only (no input gradient)."""
     if strides != 2:
-        raise NotImplementedError("Conv2DTranspose is implemented for strides=2")
+        if activation is not None:
+            raise NotImplementedError("fused activation on a Conv2DTranspose with strides != 2")
+        layer = E.ConvTDilated(_name(name, "conv2d_transpose", model), model.channels, filters, kernel_size, int(strides))
+        return KTensor(model.graph, model.graph.add("convt", layer, [model.nid], stride=int(strides)), filters)
     act, alpha = L.ACT_NONE, 0.0
     if isinstance(activation, tuple) and activation[0] == "lrelu":
         act, alpha = L.ACT_LRELU, float(activation[1])
     elif activation is not None:
         raise ValueError("unsupported activation %r" % (activation,))
-    layer = E.ConvT2D(_name(name, "conv_transp"), model.channels, filters, kernel_size, act, alpha)
+    layer = E.ConvT2D(_name(name, "conv2d_transpose", model), model.channels, filters, kernel_size, act, alpha)
     return KTensor(model.graph, model.graph.add("convt", layer, [model.nid]), filters)
 
 
@@ -183,9 +258,6 @@ def upsampling_block_attention(model, input_, scale, kernel_size, filters, name=
     """model.py:78-98: the network input, resized by scale//2 (nearest and bilinear, concatenated), gates the features through a
     sigmoid convolution; Conv2DTranspose(strides 2) + LeakyReLU(0.2); plus Conv2DTranspose(kernel scale+1, strides scale) of
     atanh(0.99999 * input)"""
-    if scale != 2:
-        raise NotImplementedError("upsampling_block_attention is instantiated for scale=2 (its to_add_input Conv2DTranspose has "
-                                  "strides=scale; strides 2 is what the engine implements)")
     near = resize_images(input_, scale // 2, "nearest", name=name + "/nearest")
     bil = resize_images(input_, scale // 2, "bilinear", name=name + "/resize_bilinear")
     up = concatenate([near, bil], name=name + "/upscaled_concat")
@@ -203,7 +275,7 @@ def batch_norm_(model, name, norm):
 
 def downsampling_block(model, kernel_size, filters, strides, name=None):
     """model.py:63-68: Conv2D(strides) + LeakyReLU(0.2)."""
-    return conv2d(model, filters, kernel_size, strides, "same", activation=("lrelu", 0.2), name=_name(name, "downsampling"))
+    return conv2d(model, filters, kernel_size, strides, "same", activation=("lrelu", 0.2), name=name)
 
 
 def upsampling_block(model, kernel_size, filters, strides, name=""):
@@ -230,12 +302,18 @@ def build_model(inputs, outputs, name="model", seed=7):
             for kind, layer, _, _ in g.nodes:
                 if layer is not None:
                     self._add(layer)
-            # nodes computed from the network input alone (concat / atanh of the input): data, no gradient flows to them
+            # nodes computed from the network input alone (resized / concatenated / cropped / atanh'd input): data, no gradient flows to them
             self.const = {0}
             for i, (kind, layer, ins, _) in enumerate(g.nodes):
-                if kind in ("concat", "atanh") and all(j in self.const for j in ins):
+                if kind in ("concat", "atanh", "resize", "crop") and all(j in self.const for j in ins):
                     self.const.add(i)
+            self.has_dropout = any(kind == "dropout" and 0.0 < a["rate"] < 1.0 for kind, _, _, a in g.nodes)
+            self._drop_step = None           # device-side step counter of the dropout masks
             self._finish()
+
+        def dropout_masks(self, tape):
+            """{Dropout layer name: uint8 NCHW keep-mask of the last training forward} (what a parity check feeds the oracle)"""
+            return {g.nodes[i][3]["name"]: t for i, t in tape.items() if g.nodes[i][0] == "dropout" and t is not None}
 
         def _out_shape(self, s):
             h, w = s[0], s[1]
@@ -248,17 +326,28 @@ def build_model(inputs, outputs, name="model", seed=7):
                     oh, ow, _, _ = layer.out_hw(ih, iw)
                     shapes[i] = (oh, ow)
                 elif kind == "convt":
-                    shapes[i] = (2 * ih, 2 * iw)
+                    shapes[i] = (g.nodes[i][3].get("stride", 2) * ih, g.nodes[i][3].get("stride", 2) * iw)
                 elif kind == "gate":
                     shapes[i] = shapes[ins[1]]
+                elif kind == "resize":
+                    shapes[i] = (ih * g.nodes[i][3]["factor"], iw * g.nodes[i][3]["factor"])
+                elif kind == "crop":
+                    (t, b), (l, r) = g.nodes[i][3]["cropping"]
+                    shapes[i] = (ih - t - b, iw - l - r)
                 else:
                     shapes[i] = (ih, iw)
             oh, ow = shapes[self.out_nid]
             return (oh, ow, outputs.channels)
 
         def forward(self, x, training):
+            rt = self.rt
             vals, tape = {0: x}, {}
-            for i, (kind, layer, ins, _) in enumerate(g.nodes):
+            if training and self.has_dropout:
+                import torch
+                if self._drop_step is None:
+                    self._drop_step = torch.zeros(1, dtype=torch.int64, device=rt.device)
+                L.check(rt.lib.vcg_counter_inc(self._drop_step.data_ptr(), rt.stream), "vcg_counter_inc")
+            for i, (kind, layer, ins, attrs) in enumerate(g.nodes):
                 if kind == "input":
                     continue
                 if kind in ("conv", "convt"):
@@ -269,8 +358,45 @@ def build_model(inputs, outputs, name="model", seed=7):
                     L.check(self.rt.lib.vcg_sigmoid_gate_fwd(a.data_ptr(), m.data_ptr(), y.data_ptr(), m.numel(), self.rt.stream), "vcg_sigmoid_gate_fwd")
                     vals[i], tape[i] = y, (a, m)
                 elif kind == "concat":
-                    import torch
-                    vals[i], tape[i] = torch.cat([vals[j] for j in ins], 1), None          # NCHW: channel concatenation (memory op)
+                    parts = [vals[j] for j in ins]
+                    n_, _, h_, w_ = parts[0].shape
+                    ctot = sum(p_.shape[1] for p_ in parts)
+                    y, off = rt.empty(n_, ctot, h_, w_), 0
+                    for p_ in parts:                                       # NCHW: channel concatenation = block copies
+                        L.check(rt.lib.vcg_copy_channels(p_.data_ptr(), y.data_ptr(), n_, p_.shape[1], 0, ctot, off, p_.shape[1], h_ * w_, rt.stream),
+                                "vcg_copy_channels")
+                        off += p_.shape[1]
+                    vals[i], tape[i] = y, [p_.shape[1] for p_ in parts]
+                elif kind == "act":
+                    z = vals[ins[0]]
+                    vals[i], tape[i] = E.head_act_fwd(rt, z, attrs["head"]), z
+                elif kind == "resize":
+                    x_ = vals[ins[0]]
+                    n_, c_, h_, w_ = x_.shape
+                    f = attrs["factor"]
+                    y = rt.empty(n_, c_, h_ * f, w_ * f)
+                    L.check(rt.lib.vcg_resize2d(x_.data_ptr(), y.data_ptr(), n_ * c_, h_, w_, f, 1 if attrs["bilinear"] else 0, rt.stream), "vcg_resize2d")
+                    vals[i], tape[i] = y, None
+                elif kind == "crop":
+                    x_ = vals[ins[0]]
+                    n_, c_, h_, w_ = x_.shape
+                    (t_, b_), (l_, r_) = attrs["cropping"]
+                    y = rt.empty(n_, c_, h_ - t_ - b_, w_ - l_ - r_)
+                    L.check(rt.lib.vcg_crop2d(x_.data_ptr(), y.data_ptr(), n_ * c_, h_, w_, t_, l_, y.shape[2], y.shape[3], rt.stream), "vcg_crop2d")
+                    vals[i], tape[i] = y, (h_, w_)
+                elif kind == "dropout":
+                    x_ = vals[ins[0]]
+                    if training and 0.0 < attrs["rate"] < 1.0:
+                        import torch
+                        import zlib
+                        y = rt.empty(*x_.shape)
+                        mask = torch.empty(x_.shape, dtype=torch.uint8, device=rt.device)
+                        seed = (zlib.crc32(attrs["name"].encode()) << 20) ^ ((self._seed * 0x9E3779B1) & 0xFFFFFFFFFFFF)
+                        L.check(rt.lib.vcg_dropout_fwd(x_.data_ptr(), y.data_ptr(), mask.data_ptr(), x_.numel(), attrs["rate"], seed,
+                                                       self._drop_step.data_ptr(), rt.stream), "vcg_dropout_fwd")
+                        vals[i], tape[i] = y, mask
+                    else:
+                        vals[i], tape[i] = x_, None
                 elif kind == "atanh":
                     x_ = vals[ins[0]]
                     y = self.rt.empty(*x_.shape)
@@ -299,7 +425,42 @@ def build_model(inputs, outputs, name="model", seed=7):
                     self._acc(grads, ins[0], da)
                     self._acc(grads, ins[1], dm)
                     continue
-                if kind in ("concat", "atanh"):
+                if kind == "concat":
+                    if i in self.const:
+                        continue
+                    n_, ctot, h_, w_ = d.shape
+                    off = 0
+                    for j, cj in zip(ins, tape[i]):                       # gradient of a concatenation: its channel blocks
+                        if j not in self.const:
+                            dj = rt.empty(n_, cj, h_, w_)
+                            L.check(rt.lib.vcg_copy_channels(d.data_ptr(), dj.data_ptr(), n_, ctot, off, cj, 0, cj, h_ * w_, rt.stream), "vcg_copy_channels")
+                            self._acc(grads, j, dj)
+                        off += cj
+                    continue
+                if kind == "crop":
+                    if i in self.const:
+                        continue
+                    n_, c_, oh_, ow_ = d.shape
+                    h_, w_ = tape[i]
+                    (t_, _), (l_, _) = g.nodes[i][3]["cropping"]
+                    dx = rt.empty(n_, c_, h_, w_)
+                    L.check(rt.lib.vcg_pad2d(d.data_ptr(), dx.data_ptr(), n_ * c_, oh_, ow_, t_, l_, h_, w_, rt.stream), "vcg_pad2d")
+                    self._acc(grads, src, dx)
+                    continue
+                if kind == "dropout":
+                    if tape[i] is None:
+                        self._acc(grads, src, d)
+                    else:
+                        dx = rt.empty(*d.shape)
+                        L.check(rt.lib.vcg_dropout_bwd(d.data_ptr(), tape[i].data_ptr(), dx.data_ptr(), d.numel(), g.nodes[i][3]["rate"], rt.stream),
+                                "vcg_dropout_bwd")
+                        self._acc(grads, src, dx)
+                    continue
+                if kind == "act":
+                    if src not in self.const:
+                        self._acc(grads, src, E.head_act_bwd(rt, tape[i], d, g.nodes[i][3]["head"]))
+                    continue
+                if kind in ("atanh", "resize"):
                     if i not in self.const:
                         raise NotImplementedError("gradients through %s of non-input tensors" % kind)
                     continue
@@ -353,11 +514,9 @@ def make_upscaler_orig_functional(output_image_shape, kernel_size=5, filters=64,
 
 
 def make_upscaler_attention(output_image_shape, kernel_size=5, filters=64, upscale_factor=4, res_block_num=16, norm="batch", seed=7):
-    """make_upscaler_attention (model.py:299-328) -- the default generator of train_gan3.py (:55 'resnet-att') -- written block by
-    block as the reference writes it.  The up-sampling attention block's second Conv2DTranspose has strides = 2**(index+1): the
-    engine implements strides 2, i.e. upscale_factor=2 (one block, the configuration BASELINE.json names); other factors raise."""
-    if upscale_factor != 2:
-        raise NotImplementedError("make_upscaler_attention is instantiated for upscale_factor=2 (Conv2DTranspose strides 4 is not built)")
+    """make_upscaler_attention (model.py:299-328) -- the default generator of train_gan3.py (:55 'resnet-att', default -d 4) -- written
+    block by block as the reference writes it.  Up-sampling block i resizes the input by 2**i (nearest and bilinear) for its attention
+    and adds Conv2DTranspose(kernel 2**(i+1)+1, strides 2**(i+1)) of atanh(0.99999 * input) (E.ConvTDilated for strides 4)."""
     input_image_shape = (output_image_shape[0] // upscale_factor, output_image_shape[1] // upscale_factor, output_image_shape[2])
     upscale_times = int(math.log(upscale_factor, 2))
     upscaler_input = Input(shape=input_image_shape, name="initial/input")

@@ -72,6 +72,13 @@ SIGNATURES = {
     "vcg_mean_reduce": (c_int, [_P, c_size_t, _P, _P, c_size_t, _P]),
     "vcg_pixel_loss": (c_int, [_P, _P, c_size_t, c_int, c_float, _P, _P, _P, c_size_t, _P]),
     "vcg_dilate2d": (c_int, [_P, _P, c_size_t, c_int, c_int, c_int, _P]),
+    "vcg_resize2d": (c_int, [_P, _P, c_size_t, c_int, c_int, c_int, c_int, _P]),
+    "vcg_crop2d": (c_int, [_P, _P, c_size_t, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    "vcg_pad2d": (c_int, [_P, _P, c_size_t, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    "vcg_copy_channels": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_size_t, _P]),
+    "vcg_dropout_fwd": (c_int, [_P, _P, _P, c_size_t, c_float, ctypes.c_uint64, _P, _P]),
+    "vcg_dropout_bwd": (c_int, [_P, _P, _P, c_size_t, c_float, _P]),
+    "vcg_counter_inc": (c_int, [_P, _P]),
     "vcg_fill": (c_int, [_P, c_size_t, c_float, _P]),
     "vcg_axpby": (c_int, [_P, _P, c_size_t, c_float, c_float, _P]),
     "vcg_adam_keras_multi": (c_int, [_P, _P, _P, _P, c_size_t, c_float, c_float, c_float, c_float, c_float, _P]),

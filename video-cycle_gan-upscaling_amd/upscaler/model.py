@@ -1202,6 +1202,11 @@ def compile_training_model(upscaler, loss, optimizer=_DEFAULT_ADAM):
 # =================================================================================================
 # functional block API (model.py:15-27, 63-75) -- see _graph.py
 # =================================================================================================
-from ._graph import (Input, add, atanh_scaled, batch_norm, build_model, concatenate, conv2d, conv2d_transpose,  # noqa: E402,F401
-                     downsampling_block, leaky_relu, make_upscaler_attention, make_upscaler_orig_functional, multiply_sigmoid,
-                     prelu, residual_block, residual_block_attention, resize_images, upsampling_block, upsampling_block_attention)
+from ._graph import (Input, activation, add, atanh_scaled, batch_norm, batch_norm_prelu, build_model, concatenate, conv2d,  # noqa: E402,F401
+                     conv2d_transpose, cropping2d, downsampling_block, dropout, leaky_relu, make_upscaler_attention,
+                     make_upscaler_orig_functional, multiply_sigmoid, prelu, residual_block, residual_block_attention, resize_images,
+                     upsampling_block, upsampling_block_attention)
+# the other generators train_gan3.py offers behind -gm (model.py:332-363, 505-827) -- see _generators.py
+from ._generators import (concatenate_layers, downsampling_unetish_block, find_crop_shape, make_upscaler_skip_con,  # noqa: E402,F401
+                          make_upscaler_unetish, make_upscaler_unetish_add, make_upscaler_unetish_complex, same_size_unetish_block,
+                          sum_layers, upsampling_unetish_block)
