@@ -5,6 +5,7 @@ CPU restatement of the other generator topologies train_gan3.py offers behind ``
   make_upscaler_unetish           upscaling/upscaler/model.py:570-634   (blocks :505-566)
   make_upscaler_unetish_add       upscaling/upscaler/model.py:642-716
   make_upscaler_unetish_complex   upscaling/upscaler/model.py:743-827
+  make_upscaler_incep_resnet      upscaling/upscaler/model.py:443-497   (blocks :372-440)
 
 Written define-by-run: ``Net`` looks every layer's weights up by its Keras name in a flat dict (the weight-exchange format of
 oracle/models.py); run with ``rng`` set, missing weights are created the way Keras initialises them, so one function both counts /
@@ -54,7 +55,8 @@ class Net:
     def conv2d(self, x, filters, k, stride=1, name=None):
         n = self._name(name, "conv2d")
         cin = x.shape[1]
-        self._get(n + "/kernel", lambda t: M._conv_w(t, self.rng, n, k, k, cin, filters))
+        kh, kw = k if isinstance(k, tuple) else (k, k)
+        self._get(n + "/kernel", lambda t: M._conv_w(t, self.rng, n, kh, kw, cin, filters))
         return K.conv2d(x, self.w[n + "/kernel"], self.w[n + "/bias"], stride, "same")
 
     def conv2d_transpose(self, x, filters, k, stride=2, name=None):
@@ -222,6 +224,56 @@ def upscaler_unetish_complex(net, x_nhwc, kernel_size=5, upscale_factor=4, step_
         if step < 2:
             model = net.dropout(model, dropout_rate, p + "/Dropout")
     return _final_crop(model, x.shape[2] * upscale_factor, x.shape[3] * upscale_factor).permute(0, 2, 3, 1)
+
+
+# ---- model.py:372-497 ------------------------------------------------------------------------------------------
+def inception_mini_resblock(net, model, filters, name, kernel_size, batch_normalisation=True):
+    if batch_normalisation:
+        model = net.bn(model, name + "/batch_norm")
+    model = net.prelu(model, name + "/prelu")
+    return net.conv2d(model, filters, tuple(kernel_size), 1, name + "/%dx%d" % (kernel_size[0], kernel_size[1]))
+
+
+def inception_resblock_3path(net, model, filters, name, kernel_size=3, bn=True):
+    gen, k = model, kernel_size
+    a = inception_mini_resblock(net, model, int(filters * 0.5), name + "/a/1", (1, 1), bn)
+    b = inception_mini_resblock(net, model, int(filters * 0.5), name + "/b/1", (1, 1), bn)
+    b = inception_mini_resblock(net, b, int(filters * 0.5), name + "/b/2", (k, k), bn)
+    c = inception_mini_resblock(net, model, int(filters * 0.5), name + "/c/1", (1, 1), bn)
+    c = inception_mini_resblock(net, c, int(filters * 0.75), name + "/c/2", (k, k), bn)
+    c = inception_mini_resblock(net, c, filters, name + "/c/3", (k, k), bn)
+    model = net.conv2d(torch.cat([a, b, c], 1), filters, 1, 1, name + "/final/1x1")
+    return gen + model
+
+
+def inception_resblock_2path(net, model, filters, name, kernel_size=7, bn=True):
+    gen, k = model, kernel_size
+    a = inception_mini_resblock(net, model, int(filters * 0.5), name + "/a/1", (1, 1), bn)
+    b = inception_mini_resblock(net, model, int(filters * 0.3), name + "/b/1", (1, 1), bn)
+    b = inception_mini_resblock(net, b, int(filters * 0.4), name + "/b/2", (1, k), bn)
+    b = inception_mini_resblock(net, b, int(filters * 0.5), name + "/b/3", (k, 1), bn)
+    model = net.conv2d(torch.cat([a, b], 1), filters, 1, 1, name + "/final/1x1")
+    return gen + model
+
+
+def upscaler_incep_resnet(net, x_nhwc, filters=64, upscale_factor=4, a_block_type="3path", a_block_num=5, a_block_kernel=3,
+                          b_block_type="2path", b_block_num=10, b_block_kernel=7, c_block_type="2path", c_block_num=5, c_block_kernel=3):
+    """model.py:443-497"""
+    x = x_nhwc.permute(0, 3, 1, 2)
+    model = net.conv2d(x, filters, 9, 1, "initial/conv/9x9")
+    upsc_model = model
+    for tag, btype, num, kern in (("A", a_block_type, a_block_num, a_block_kernel), ("B", b_block_type, b_block_num, b_block_kernel),
+                                  ("c", c_block_type, c_block_num, c_block_kernel)):
+        for index in range(num):
+            if btype == "3path":
+                model = inception_resblock_3path(net, model, filters, "inc_res_block/%s/3p/%d" % (tag, index), kern)
+            elif btype == "2path":
+                model = inception_resblock_2path(net, model, filters, "inc_res_block/%s/2p/%d" % (tag, index), kern)
+    model = net.bn(net.conv2d(model, filters, c_block_kernel, 1, "prefinal/conv2d"), "prefinal/batch_norm")
+    model = upsc_model + model
+    for index in range(int(math.log(upscale_factor, 2))):
+        model = upsampling_block(net, model, c_block_kernel, 256, 2, "upscaling/%d/block" % index)
+    return torch.tanh(net.conv2d(model, 3, 9, 1, "final/conv")).permute(0, 2, 3, 1)
 
 
 def init_weights(fn, in_shape, seed, **kw):

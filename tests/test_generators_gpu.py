@@ -114,6 +114,33 @@ def test_skip_con_matches_oracle_and_mirrors_the_reference_error(rt):
     _check(rt, "make_upscaler_skip_con", PM.make_upscaler_skip_con((32, 48, 3), **kw), OG.upscaler_skip_con, kw, (16, 24), (32, 48), 9)
 
 
+def test_incep_resnet_matches_oracle(rt):
+    """make_upscaler_incep_resnet (model.py:443-497) with one block of each kind the reference's defaults use: 3-path k3 (1x1, 3x3),
+    2-path k7 (1x1, 1x7, 7x1 on 19- / 25- / 32-channel paths), 2-path k3 (1x3, 3x1)"""
+    from oracle import generators as OG
+    from upscaler import model as PM
+    kw = dict(filters=64, upscale_factor=2, a_block_num=1, b_block_num=1, c_block_num=1)
+    _check(rt, "make_upscaler_incep_resnet", PM.make_upscaler_incep_resnet((40, 72, 3), **kw), OG.upscaler_incep_resnet, kw, (20, 36), (40, 72), 11)
+
+
+def test_incep_resnet_other_block_choices(rt):
+    """3-path with kernel 5 and 2-path with kernel 5 (train_gan3.py --a_block_kernel ... :88-99): inference against the oracle"""
+    from oracle import generators as OG, models as M
+    from upscaler import model as PM
+    kw = dict(filters=64, upscale_factor=2, a_block_type="2path", a_block_num=1, a_block_kernel=5, b_block_type="3path", b_block_num=1, b_block_kernel=5,
+              c_block_num=0)
+    G = PM.make_upscaler_incep_resnet((32, 48, 3), **kw)
+    gw = _randomise(OG.init_weights(OG.upscaler_incep_resnet, (16, 24, 3), 4, **kw), 5)
+    assert G.count_params() == M.count_params(gw)
+    G.set_weights_dict(gw)
+    x = (np.random.RandomState(6).randint(0, 256, (2, 16, 24, 3)) / 127.5 - 1).astype(np.float32)
+    with torch.no_grad():
+        y0 = OG.upscaler_incep_resnet(OG.Net(M.to_torch(gw, torch.float64), False), torch.tensor(x, dtype=torch.float64), **kw)
+    e0 = rel_err(torch.tensor(G.predict(x)), y0)
+    report("make_upscaler_incep_resnet (2-path k5 / 3-path k5): predict err=%.2e" % e0)
+    assert e0 < 1e-3
+
+
 def test_dropout_masks_change_every_step_and_vanish_at_inference(rt):
     from upscaler import _engine as E, model as PM
     G = PM.make_upscaler_unetish((44, 60, 3), **U)

@@ -91,6 +91,11 @@ def test_reference_signatures_are_mirrored():
                                                         ("downscale_times", 5), ("initial_step_filter_count", 48), ("dropout_rate", 0.1)]
     assert params(PM.make_upscaler_unetish_complex)[:7] == [("output_image_shape", inspect._empty), ("kernel_size", 5), ("upscale_factor", 4),
                                                             ("step_size", 4), ("downscale_times", 3), ("initial_step_filter_count", 32), ("dropout_rate", 0.1)]
+    # :443-449
+    assert params(PM.make_upscaler_incep_resnet)[:12] == [("output_image_shape", inspect._empty), ("filters", 64), ("upscale_factor", 4),
+                                                          ("a_block_type", "3path"), ("a_block_num", 5), ("a_block_kernel", 3),
+                                                          ("b_block_type", "2path"), ("b_block_num", 10), ("b_block_kernel", 7),
+                                                          ("c_block_type", "2path"), ("c_block_num", 5), ("c_block_kernel", 3)]
     for f in (PM.same_size_unetish_block, PM.downsampling_unetish_block, PM.upsampling_unetish_block):
         assert params(f) == [("model", inspect._empty), ("kernel_size", inspect._empty), ("filters", inspect._empty), ("strides", inspect._empty),
                              ("name", inspect._empty), ("dropout_rate", 0.1)]

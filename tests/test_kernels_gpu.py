@@ -63,6 +63,15 @@ CONV_CASES = [
     (256, 3, 9, 1, "same", 1, 20, 64),       # width % 64 == 0: the row-chain kernel (conv_rowchain.hip)
     (256, 3, 9, 1, "same", 2, 70, 128),      # two strips, several row segments
     (256, 1, 9, 1, "same", 1, 9, 64),
+    # the inception-resnet generator's shapes (model.py:372-440): 1x1, 1xk / kx1, odd channel counts
+    (64, 19, (1, 1), 1, "same", 2, 13, 45),
+    (19, 25, (1, 7), 1, "same", 2, 13, 45),
+    (25, 32, (7, 1), 1, "same", 2, 13, 45),
+    (128, 64, (1, 1), 1, "same", 1, 20, 36),
+    (19, 25, (1, 3), 1, "same", 1, 9, 33),
+    (25, 32, (3, 1), 1, "same", 1, 9, 33),
+    (19, 25, (1, 5), 1, "same", 3, 16, 32),
+    (25, 300, (5, 1), 1, "same", 1, 16, 40),   # more than one weight-gradient column block (256 / 5 channels each)
 ]
 
 
@@ -71,7 +80,7 @@ def test_conv2d_fwd_dgrad_wgrad(rt, cin, cout, k, stride, padding, n, h, w):
     from upscaler import _engine as E, _lib as L
     from oracle import keras_ops as K
     layer = E.Conv2D("c", cin, cout, k, stride, padding)
-    ps, wd = _standalone(rt, layer, seed=cin + cout + k)
+    ps, wd = _standalone(rt, layer, seed=cin + cout + (k if isinstance(k, int) else 10 * k[0] + k[1]))
     g = torch.Generator().manual_seed(1)
     x = torch.randn(n, cin, h, w, generator=g, dtype=torch.float64)
     xr = x.clone().requires_grad_(True)
@@ -88,7 +97,7 @@ def test_conv2d_fwd_dgrad_wgrad(rt, cin, cout, k, stride, padding, n, h, w):
     e_dx = rel_err(dx, xr.grad)
     e_dw = rel_err(ps.grad("c/kernel"), wk.grad)
     e_db = rel_err(ps.grad("c/bias"), bk.grad)
-    report("conv2d cin=%d cout=%d k=%d s=%d pad=%s n=%d %dx%d  fwd=%.2e dx=%.2e dw=%.2e db=%.2e"
+    report("conv2d cin=%d cout=%d k=%s s=%d pad=%s n=%d %dx%d  fwd=%.2e dx=%.2e dw=%.2e db=%.2e"
            % (cin, cout, k, stride, padding, n, h, w, e_f, e_dx, e_dw, e_db))
     assert e_f < TOL and e_dx < TOL and e_dw < TOL and e_db < TOL
 

@@ -219,3 +219,20 @@ def test_dropout_restatement_is_identity_outside_training_and_scales_inside():
     assert torch.equal(G.Net({}, True).dropout(x, 0.0, "d"), x)                         # keras.layers.Dropout.call: 0 < rate < 1
     y = G.Net({}, True, masks={"d": mask}).dropout(x, 0.25, "d")
     assert torch.equal(y, torch.where(mask, x / 0.75, torch.zeros_like(x)))
+
+
+def test_incep_resnet_parameter_count():
+    """make_upscaler_incep_resnet (model.py:443-497) at its defaults, counted by hand.  Per mini block: BN 4c + PReLU c on the INPUT
+    channels, then the convolution.  3-path (k=3, f=64): a 64->32 1x1; b 64->32 1x1, 32->32 3x3; c 64->32 1x1, 32->48 3x3, 48->64 3x3;
+    concat 128 -> 64 1x1.  2-path (k, f=64): a 64->32 1x1; b 64->19 1x1, 19->25 1xk, 25->32 kx1; concat 64 -> 64 1x1."""
+    from oracle import generators as G, models as M
+    mini = lambda ci, co, t: 5 * ci + t * ci * co + co
+    p3 = lambda k: (mini(64, 32, 1) + mini(64, 32, 1) + mini(32, 32, k * k) + mini(64, 32, 1) + mini(32, 48, k * k) + mini(48, 64, k * k)
+                    + 128 * 64 + 64)
+    p2 = lambda k: mini(64, 32, 1) + mini(64, 19, 1) + mini(19, 25, k) + mini(25, 32, k) + 64 * 64 + 64
+    expected = (81 * 3 * 64 + 64) + 5 * p3(3) + 10 * p2(7) + 5 * p2(3) + (9 * 64 * 64 + 64) + 256 \
+        + (9 * 64 * 256 + 256) + (9 * 256 * 256 + 256) + (81 * 256 * 3 + 3)
+    w = G.init_weights(G.upscaler_incep_resnet, (8, 8, 3), 1)
+    assert M.count_params(w) == expected
+    assert w["inc_res_block/B/2p/0/b/2/1x7/kernel"].shape == (1, 7, 19, 25) and w["inc_res_block/B/2p/0/b/3/7x1/kernel"].shape == (7, 1, 25, 32)
+    assert "inc_res_block/c/2p/4/final/1x1/kernel" in w                       # the third group is tagged 'c' in lower case (model.py:479,481)

@@ -25,7 +25,8 @@ int check_desc(const vcg_conv_desc* d) {
 }
 
 // the small-M (channel,kx)-in-rows kernel pays off when <= 32/KW output channels are produced
-inline bool use_smallm(int mch, int kw, int stride) { return stride == 1 && mch * kw <= 32; }
+// the small-M kernel (<= 32 / kw result channels) is instantiated for the square kernels only
+inline bool use_smallm(int mch, int kh, int kw, int stride) { return stride == 1 && kh == kw && kh >= 3 && mch * kw <= 32; }
 
 }  // namespace
 
@@ -54,7 +55,7 @@ int vcg_conv2d_fwd(const vcg_conv_desc* d, const float* x, const float* w_hwio, 
     VCG_CHECK_PTR(x); VCG_CHECK_PTR(w_hwio); VCG_CHECK_PTR(y);
     // output extent must be consistent with the pads: last tap of the last output stays < h + k
     if ((d->oh - 1) * d->stride - d->pad_top >= d->h || (d->ow - 1) * d->stride - d->pad_left >= d->w) return VCG_E_SHAPE;
-    const bool sm = use_smallm(d->cout, d->kw, d->stride);
+    const bool sm = use_smallm(d->cout, d->kh, d->kw, d->stride);
     // HWIO = [tap][cin][cout]: element (mch=co, kc=ci, tap) at tap*cin*cout + ci*cout + co
     return vcg_internal_conv(x, w_hwio, y, d->n, d->cin, d->h, d->w, d->cout, d->oh, d->ow, d->kh, d->kw, d->stride,
                              d->pad_top, d->pad_left, 0, ep, sm ? 1 : 0, d->cin * d->cout, 1, d->cout,
@@ -72,7 +73,7 @@ int vcg_conv2d_dgrad(const vcg_conv_desc* d, const float* dy, const float* w_hwi
     if (d->stride == 1) {
         // dx[ci][i] = sum_{co,k'} dy[co][i + k' - (K-1-p)] * W[K-1-k'][ci][co]
         const int pt = d->kh - 1 - d->pad_top, pl = d->kw - 1 - d->pad_left;
-        if (use_smallm(d->cin, d->kw, 1)) {
+        if (use_smallm(d->cin, d->kh, d->kw, 1)) {
             VCG_CHECK_PTR(w_hwio);
             // rows = (ci, kx); element (mch=ci, kc=co, tap) of HWIO at tap*cin*cout + ci*cout + co
             return vcg_internal_conv(dy, w_hwio, dx, d->n, d->cout, d->oh, d->ow, d->cin, d->h, d->w, d->kh, d->kw, 1,

@@ -584,5 +584,15 @@ int vcg_internal_conv(const float* x, const float* w, float* y, int n, int cin, 
     if (kh == 5 && kw == 5 && stride == 2) return launch_conv<5, 5, 2, 4, 1>(p, st);
     if (kh == 5 && kw == 5 && stride == 3) return launch_conv<5, 5, 3, 4, 1>(p, st);   // sparse_512 blocks 2-6 (model.py:971-987)
     if (kh == 9 && kw == 9 && stride == 1) return launch_conv<9, 9, 1, 4, 1>(p, st);
+    // make_upscaler_incep_resnet (model.py:372-440): 1x1, and the 1xk / kx1 pairs of the 2-path blocks (and their data gradients)
+    if (stride == 1) {
+        if (kh == 1 && kw == 1) return launch_conv<1, 1, 1, 8, 1>(p, st);
+        if (kh == 1 && kw == 3) return launch_conv<1, 3, 1, 8, 1>(p, st);
+        if (kh == 3 && kw == 1) return launch_conv<3, 1, 1, 8, 1>(p, st);
+        if (kh == 1 && kw == 5) return launch_conv<1, 5, 1, 8, 1>(p, st);
+        if (kh == 5 && kw == 1) return launch_conv<5, 1, 1, 8, 1>(p, st);
+        if (kh == 1 && kw == 7) return launch_conv<1, 7, 1, 8, 1>(p, st);
+        if (kh == 7 && kw == 1) return launch_conv<7, 1, 1, 8, 1>(p, st);
+    }
     return VCG_E_UNSUPPORTED;
 }

@@ -1,7 +1,7 @@
 // Weight gradient as a pixel-contraction GEMM on v_mfma_f32_32x32x2_f32, NCHW.
 //
 //   R[m][j] = sum_{n, (ay,ax)}  A[n][m][ay][ax] * B[n][jc(j)][ay*S + ky(j) - PT][ax*S + kx(j) - PL]
-//   j = jc*T + ky*K + kx  (taps flipped when FLIP)
+//   j = jc*T + ky*KW + kx  (taps flipped when FLIP); kernels need not be square (1x7 / 7x1 / 1x1 of the inception-resnet generator)
 //
 // normal orientation  : A = dy (m = out channel), B = x  (jc = in channel)          -> any stride
 // swapped orientation : A = x  (m = in channel),  B = dy (jc = out channel), FLIP=1 -> stride 1;
@@ -41,20 +41,20 @@ struct WgradParams {
 //   MW = 1: waves split the m-tiles too (wave = 1 m-tile x NJ j-tiles, JTILES = NW/2*NJ): the layout for the
 //           64-channel 3x3 / 5x5 blocks whose 18 / 26 j-tiles need 144-208 accumulator registers per wave.
 // Which layout serves which shape was measured (profiles/r01_kbench.txt).
-template <int S, int NW, int NJ, int MW, int TH, int K>
+template <int S, int NW, int NJ, int MW, int TH, int KH, int KW>
 struct WgCfg {
-    static constexpr int T = K * K;
+    static constexpr int T = KH * KW;
     static constexpr int NT = 64 * NW;                   // threads per workgroup
     static constexpr int JTILES = (MW == 2 ? NW : NW / 2) * NJ;   // j-tiles per block
     static constexpr int JCMAX = (JTILES * 32) / T;      // B channels per block
     static constexpr int AST = TH * 32 + 1;              // odd stride between m rows of the A tile
-    static constexpr int BH = (TH - 1) * S + K;
-    static constexpr int BW = 31 * S + K;
-    // conflict-free gather: row stride = K and plane stride = K*K (mod 32) put element (jc,ky,kx) of a lane on
-    // bank (T*jc + K*ky + kx) mod 32 = j mod 32, i.e. the 32 lanes of a j-tile hit 32 different banks
+    static constexpr int BH = (TH - 1) * S + KH;
+    static constexpr int BW = 31 * S + KW;
+    // conflict-free gather: row stride = KW and plane stride = KH*KW (mod 32) put element (jc,ky,kx) of a lane on
+    // bank (T*jc + KW*ky + kx) mod 32 = j mod 32, i.e. the 32 lanes of a j-tile hit 32 different banks
     static constexpr int round_to(int v, int r) { return v + ((r - v % 32) % 32 + 32) % 32; }
-    static constexpr int BRS = round_to(BW, K % 32);
-    static constexpr int BPS = round_to(BH * BRS, (K * K) % 32);
+    static constexpr int BRS = round_to(BW, KW % 32);
+    static constexpr int BPS = round_to(BH * BRS, T % 32);
     static constexpr int A_ELEMS = 64 * TH * 32;
     static constexpr int B_ELEMS = JCMAX * BH * BW;
     static constexpr int A_PT = (A_ELEMS + NT - 1) / NT;
@@ -66,13 +66,14 @@ struct WgCfg {
     static constexpr int QSEG = BW / 32, REM = BW % 32;
     static constexpr int RPT = (ROWS + RG - 1) / RG;
     static constexpr int HPT = (ROWS * REM + NT - 1) / NT;
+    static constexpr int REMD = REM > 0 ? REM : 1;       // divisor of the remainder pass (which is empty when BW is a multiple of 32)
     static constexpr int B_PT = RPT * QSEG + HPT;
     static constexpr size_t LDS_BYTES = ((size_t)64 * AST + (size_t)JCMAX * BPS + 64) * sizeof(float);
 };
 
-template <int S, int NW, int NJ, int MW, int TH, int K>
+template <int S, int NW, int NJ, int MW, int TH, int KH, int KW>
 __global__ __launch_bounds__(64 * NW, (MW * NJ * 16 > 100 ? 1 : 2)) void wgrad_kernel(const WgradParams p) {
-    using C = WgCfg<S, NW, NJ, MW, TH, K>;
+    using C = WgCfg<S, NW, NJ, MW, TH, KH, KW>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* s_a = smem;                 // [64][AST]
     float* s_b = smem + 64 * C::AST;   // [JCMAX][BH][BRS] (plane stride BPS)
@@ -95,8 +96,8 @@ __global__ __launch_bounds__(64 * NW, (MW * NJ * 16 > 100 ? 1 : 2)) void wgrad_k
         int o = 0;
         if (j < jvalid) {
             const int jc = j / C::T, t = j % C::T;
-            int ky = t / K, kx = t % K;
-            if (p.flip) { ky = K - 1 - ky; kx = K - 1 - kx; }
+            int ky = t / KW, kx = t % KW;
+            if (p.flip) { ky = KH - 1 - ky; kx = KW - 1 - kx; }
             o = jc * C::BPS + ky * C::BRS + kx;
         }
         boff[i] = o + half * S;
@@ -154,7 +155,7 @@ __global__ __launch_bounds__(64 * NW, (MW * NJ * 16 > 100 ? 1 : 2)) void wgrad_k
 #pragma unroll
         for (int i = 0; i < C::HPT; ++i) {
             const int e = tid + i * C::NT;
-            const int row = e / C::REM, c = C::QSEG * 32 + e % C::REM;
+            const int row = e / C::REMD, c = C::QSEG * 32 + e % C::REMD;
             const int jc = row / C::BH, r = row % C::BH;
             const int by = by0 + r, bx = bx0 + c;
             const bool ok = row < C::ROWS && jc < jc_here && by >= 0 && by < p.bh && bx >= 0 && bx < p.bw;
@@ -183,7 +184,7 @@ __global__ __launch_bounds__(64 * NW, (MW * NJ * 16 > 100 ? 1 : 2)) void wgrad_k
 #pragma unroll
         for (int i = 0; i < C::HPT; ++i) {
             const int e = tid + i * C::NT;
-            const int row = e / C::REM, c = C::QSEG * 32 + e % C::REM;
+            const int row = e / C::REMD, c = C::QSEG * 32 + e % C::REMD;
             if (row < C::ROWS) {
                 const int jc = row / C::BH, r = row % C::BH;
                 s_b[jc * C::BPS + r * C::BRS + c] = rb[C::RPT * C::QSEG + i];
@@ -287,17 +288,19 @@ __global__ __launch_bounds__(256) void wgrad_db_reduce_kernel(const float* dbpar
 }
 
 struct Plan {
-    int S, NW, NJ, MW, TH, K, jc, m_blocks, j_blocks, slabs, tiles_x, tiles_y, tiles_total, tiles_per_slab;
+    int S, NW, NJ, MW, TH, KH, KW, jc, m_blocks, j_blocks, slabs, tiles_x, tiles_y, tiles_total, tiles_per_slab;
     int m_pad, j_pad;
     size_t ws_part_bytes, ws_bytes;
     bool ok;
 };
 
 // wave layout per kernel size / stride (measured choices): NW waves, NJ j-tiles per wave, MW m-tiles per wave
-inline void pick_layout(int K, int S, int jtot, int* nw, int* nj, int* mw) {
+inline void pick_layout(int KH, int KW, int S, int jtot, int* nw, int* nj, int* mw) {
     *mw = 2;
     if (jtot <= 64) { *nw = 2; *nj = 1; return; }          // 3-channel first layers, 1-channel head
-    switch (K) {
+    if (KH != KW) { *nw = 4; *nj = 2; return; }            // 1xk / kx1 (inception-resnet paths): the small layout, 256 / T channels per block
+    switch (KH) {
+        case 1: *nw = 4; *nj = 2; return;                                                             // 1x1: 256 channels per block
         case 3: if (jtot <= 256) { *nw = 4; *nj = 2; } else { *nw = 4; *nj = 9; *mw = 1; } return;   // 18 tiles = 64 channels
         case 4: if (S == 2) { *nw = 4; *nj = 2; } else { *nw = 4; *nj = 8; *mw = 1; } return;        // 8 tiles = 16 ch / 16 tiles = 32 ch
         case 5: if (jtot <= 256 || S == 3) { *nw = 4; *nj = 2; } else { *nw = 4; *nj = 13; *mw = 1; } return;  // 26 tiles = 33 channels (stride 3: small layout)
@@ -309,11 +312,13 @@ inline void pick_layout(int K, int S, int jtot, int* nw, int* nj, int* mw) {
 Plan make_plan(int n, int mtot, int ah, int aw, int jctot, int kh, int kw, int S) {
     Plan pl{};
     pl.ok = false;
-    if (kh != kw || S < 1 || S > 3 || (S == 3 && kh != 5) || (kh == 9 && S != 1)) return pl;
+    if (S < 1 || S > 3 || (S == 3 && (kh != 5 || kw != 5)) || (kh == 9 && S != 1)) return pl;
+    if (kh != kw && (S != 1 || (kh != 1 && kw != 1))) return pl;            // non-square: 1xk / kx1 at stride 1
+    if (kh == 1 && kw == 1 && S != 1) return pl;
     const int T = kh * kw;
-    pl.S = S; pl.K = kh;
+    pl.S = S; pl.KH = kh; pl.KW = kw;
     pl.TH = (S == 1) ? 2 : 1;
-    pick_layout(kh, S, jctot * T, &pl.NW, &pl.NJ, &pl.MW);
+    pick_layout(kh, kw, S, jctot * T, &pl.NW, &pl.NJ, &pl.MW);
     if (pl.NW == 0) return pl;
     const int cap = (pl.MW == 2 ? pl.NW : pl.NW / 2) * pl.NJ * 32;
     pl.jc = cap / T;
@@ -338,11 +343,11 @@ Plan make_plan(int n, int mtot, int ah, int aw, int jctot, int kh, int kw, int S
     return pl;
 }
 
-template <int S, int NW, int NJ, int MW, int TH, int K>
+template <int S, int NW, int NJ, int MW, int TH, int KH, int KW>
 int launch_wgrad(const WgradParams& p, int grid, hipStream_t st) {
-    using C = WgCfg<S, NW, NJ, MW, TH, K>;
+    using C = WgCfg<S, NW, NJ, MW, TH, KH, KW>;
     static_assert(C::LDS_BYTES <= 160 * 1024, "wgrad tile does not fit the 160 KiB LDS");
-    auto kern = wgrad_kernel<S, NW, NJ, MW, TH, K>;
+    auto kern = wgrad_kernel<S, NW, NJ, MW, TH, KH, KW>;
     if (C::LDS_BYTES > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES);
@@ -378,9 +383,10 @@ int vcg_internal_wgrad(const float* A, const float* B, float* dw, float* db, int
     p.m_pad = pl.m_pad; p.j_pad = pl.j_pad;
     const int grid = pl.slabs * pl.m_blocks * pl.j_blocks;
     int rc = VCG_E_UNSUPPORTED;
-#define VCG_WG(S_, NW_, NJ_, MW_, TH_, K_)                                                          \
-    if (S == S_ && pl.NW == NW_ && pl.NJ == NJ_ && pl.MW == MW_ && pl.K == K_ && pl.TH == TH_) \
-    rc = launch_wgrad<S_, NW_, NJ_, MW_, TH_, K_>(p, grid, st)
+#define VCG_WG2(S_, NW_, NJ_, MW_, TH_, KH_, KW_)                                                                        \
+    if (S == S_ && pl.NW == NW_ && pl.NJ == NJ_ && pl.MW == MW_ && pl.KH == KH_ && pl.KW == KW_ && pl.TH == TH_) \
+    rc = launch_wgrad<S_, NW_, NJ_, MW_, TH_, KH_, KW_>(p, grid, st)
+#define VCG_WG(S_, NW_, NJ_, MW_, TH_, K_) VCG_WG2(S_, NW_, NJ_, MW_, TH_, K_, K_)
     VCG_WG(1, 2, 1, 2, 2, 3); VCG_WG(1, 4, 2, 2, 2, 3); VCG_WG(1, 4, 9, 1, 2, 3);
     VCG_WG(2, 2, 1, 2, 1, 3); VCG_WG(2, 4, 2, 2, 1, 3); VCG_WG(2, 4, 9, 1, 1, 3);
     VCG_WG(1, 2, 1, 2, 2, 4); VCG_WG(1, 4, 8, 1, 2, 4);
@@ -389,6 +395,12 @@ int vcg_internal_wgrad(const float* A, const float* B, float* dw, float* db, int
     VCG_WG(2, 4, 2, 2, 1, 5); VCG_WG(2, 4, 13, 1, 1, 5);
     VCG_WG(3, 4, 2, 2, 1, 5);            // sparse_512 (model.py:971-987): 5x5 stride 3
     VCG_WG(1, 4, 2, 2, 2, 9);
+    // make_upscaler_incep_resnet (model.py:372-440): 1x1, and the 1xk / kx1 pairs of the 2-path blocks
+    VCG_WG(1, 2, 1, 2, 2, 1); VCG_WG(1, 4, 2, 2, 2, 1);
+    VCG_WG2(1, 2, 1, 2, 2, 1, 3); VCG_WG2(1, 4, 2, 2, 2, 1, 3); VCG_WG2(1, 2, 1, 2, 2, 3, 1); VCG_WG2(1, 4, 2, 2, 2, 3, 1);
+    VCG_WG2(1, 2, 1, 2, 2, 1, 5); VCG_WG2(1, 4, 2, 2, 2, 1, 5); VCG_WG2(1, 2, 1, 2, 2, 5, 1); VCG_WG2(1, 4, 2, 2, 2, 5, 1);
+    VCG_WG2(1, 2, 1, 2, 2, 1, 7); VCG_WG2(1, 4, 2, 2, 2, 1, 7); VCG_WG2(1, 2, 1, 2, 2, 7, 1); VCG_WG2(1, 4, 2, 2, 2, 7, 1);
+#undef VCG_WG2
 #undef VCG_WG
     if (rc != VCG_OK) return rc;
     ReduceParams r{};

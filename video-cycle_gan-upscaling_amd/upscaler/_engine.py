@@ -192,39 +192,40 @@ class Layer:
 
 
 class Conv2D(Layer):
-    """keras.layers.Conv2D(+fused bias/LeakyReLU/tanh epilogue).  padding: 'same' | 'valid' | int."""
+    """keras.layers.Conv2D(+fused bias/LeakyReLU/tanh epilogue).  padding: 'same' | 'valid' | int; k: int or (kh, kw)."""
 
     def __init__(self, name, cin, cout, k, stride=1, padding="same", act=L.ACT_NONE, alpha=0.0):
         super().__init__(name)
-        self.cin, self.cout, self.k, self.stride, self.padding = cin, cout, k, stride, padding
+        self.kh, self.kw = (int(k[0]), int(k[1])) if isinstance(k, (tuple, list)) else (int(k), int(k))
+        self.cin, self.cout, self.k, self.stride, self.padding = cin, cout, self.kh, stride, padding     # k: the square layers' size
         self.act, self.alpha = act, alpha
         self.wt = None
         self._wt_valid = False
 
     def declare(self, ps):
-        ps.declare(self.name + "/kernel", (self.k, self.k, self.cin, self.cout))
+        ps.declare(self.name + "/kernel", (self.kh, self.kw, self.cin, self.cout))
         ps.declare(self.name + "/bias", (self.cout,))
 
     def init_weights(self, rng):
-        k = self.k
-        return {self.name + "/kernel": glorot_uniform(rng, (k, k, self.cin, self.cout), k * k * self.cin, k * k * self.cout),
+        t = self.kh * self.kw
+        return {self.name + "/kernel": glorot_uniform(rng, (self.kh, self.kw, self.cin, self.cout), t * self.cin, t * self.cout),
                 self.name + "/bias": np.zeros((self.cout,), np.float32)}
 
     def out_hw(self, h, w):
-        k, s = self.k, self.stride
+        kh, kw, s = self.kh, self.kw, self.stride
         if self.padding == "same":
-            oh, pt, _ = same_pads(h, k, s)
-            ow, pl, _ = same_pads(w, k, s)
+            oh, pt, _ = same_pads(h, kh, s)
+            ow, pl, _ = same_pads(w, kw, s)
         elif self.padding == "valid":
-            oh, ow, pt, pl = (h - k) // s + 1, (w - k) // s + 1, 0, 0
+            oh, ow, pt, pl = (h - kh) // s + 1, (w - kw) // s + 1, 0, 0
         else:
             p = int(self.padding)
-            oh, ow, pt, pl = (h + 2 * p - k) // s + 1, (w + 2 * p - k) // s + 1, p, p
+            oh, ow, pt, pl = (h + 2 * p - kh) // s + 1, (w + 2 * p - kw) // s + 1, p, p
         return oh, ow, pt, pl
 
     def desc(self, n, h, w):
         oh, ow, pt, pl = self.out_hw(h, w)
-        return L.ConvDesc(n, self.cin, h, w, self.cout, oh, ow, self.k, self.k, self.stride, pt, pl)
+        return L.ConvDesc(n, self.cin, h, w, self.cout, oh, ow, self.kh, self.kw, self.stride, pt, pl)
 
     def refresh(self):
         self._wt_valid = False
@@ -233,10 +234,10 @@ class Conv2D(Layer):
         """per-tap transposed kernel (kh,kw,out,in), rebuilt lazily after each parameter change"""
         rt = self.rt
         if self.wt is None:
-            self.wt = rt.empty(self.k * self.k, self.cout, self.cin)
+            self.wt = rt.empty(self.kh * self.kw, self.cout, self.cin)
         if not self._wt_valid:
             L.check(rt.lib.vcg_kernel_transpose(self.ps[self.name + "/kernel"].data_ptr(), self.wt.data_ptr(),
-                                                self.k * self.k, self.cin, self.cout, rt.stream), "vcg_kernel_transpose")
+                                                self.kh * self.kw, self.cin, self.cout, rt.stream), "vcg_kernel_transpose")
             self._wt_valid = True
         return self.wt
 

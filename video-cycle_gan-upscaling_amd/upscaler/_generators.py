@@ -7,8 +7,7 @@ reference names nothing -- same weights, same kernels):
   make_upscaler_unetish_add       model.py:642-716                       ('unetish-add')
   make_upscaler_unetish_complex   model.py:743-827                       (defined, offered by no driver)
 
-``make_upscaler_incep_resnet`` ('inc-resnet', model.py:372-497) is not built: its 1x7 / 7x1 / 1x1 convolutions on 19- and 25-channel
-paths are shapes no kernel here is instantiated for.
+  make_upscaler_incep_resnet      model.py:443-497, blocks :372-440      ('inc-resnet': 1x1 / 1xk / kx1 convolutions on 19-, 25-, 32-, 48-channel paths)
 """
 import math
 
@@ -167,3 +166,76 @@ def make_upscaler_skip_con(output_image_shape, kernel_size=5, filters=64, upscal
     model = G.concatenate([resized_input, model])
     model = G.conv2d(model, 3, 9, 1, "same", activation="tanh")
     return G.build_model(upscaler_input, model, name="upscaler_skip_con", seed=seed)
+
+
+# ---- inception-resnet (model.py:372-497) -----------------------------------------------------------------------------------------------
+def inception_mini_resblock(model, filters, name, kernel_size, batch_normalisation=True):
+    """model.py:372-382: [BatchNormalization] -> PReLU -> Conv2D(kernel_size = (kh, kw)), pre-activation order"""
+    if batch_normalisation:
+        model = G.batch_norm_prelu(model, name + "/batch_norm", name + "/prelu")
+    else:
+        model = G.prelu(model, name=name + "/prelu")
+    return G.conv2d(model, filters, tuple(kernel_size), 1, "same", name=name + "/%dx%d" % (kernel_size[0], kernel_size[1]))
+
+
+def inception_resblock_3path(model, filters, name, kernel_size=3, batch_normalisation=True):
+    """model.py:386-412"""
+    gen = model
+    path_a_filters = int(filters * 0.5)
+    path_b_filters = int(filters * 0.5)
+    path_c_filters1 = int(filters * 0.5)
+    path_c_filters2 = int(filters * 0.75)
+    path_c_filters3 = filters
+    bn, k = batch_normalisation, kernel_size
+    path_a_model = inception_mini_resblock(model, path_a_filters, name + "/a/1", (1, 1), bn)
+    path_b_model = inception_mini_resblock(model, path_b_filters, name + "/b/1", (1, 1), bn)
+    path_b_model = inception_mini_resblock(path_b_model, path_b_filters, name + "/b/2", (k, k), bn)
+    path_c_model = inception_mini_resblock(model, path_c_filters1, name + "/c/1", (1, 1), bn)
+    path_c_model = inception_mini_resblock(path_c_model, path_c_filters2, name + "/c/2", (k, k), bn)
+    path_c_model = inception_mini_resblock(path_c_model, path_c_filters3, name + "/c/3", (k, k), bn)
+    model = G.concatenate([path_a_model, path_b_model, path_c_model], name=name + "/final/concat")
+    model = G.conv2d(model, filters, 1, 1, "same", name=name + "/final/1x1")
+    return G.add([gen, model], name=name + "/final/add")
+
+
+def inception_resblock_2path(model, filters, name, kernel_size=7, batch_normalisation=True):
+    """model.py:416-439"""
+    gen = model
+    path_a_filters = int(filters * 0.5)
+    path_b_filters1 = int(filters * 0.3)
+    path_b_filters2 = int(filters * 0.4)
+    path_b_filters3 = int(filters * 0.5)
+    bn, k = batch_normalisation, kernel_size
+    path_a_model = inception_mini_resblock(model, path_a_filters, name + "/a/1", (1, 1), bn)
+    path_b_model = inception_mini_resblock(model, path_b_filters1, name + "/b/1", (1, 1), bn)
+    path_b_model = inception_mini_resblock(path_b_model, path_b_filters2, name + "/b/2", (1, k), bn)
+    path_b_model = inception_mini_resblock(path_b_model, path_b_filters3, name + "/b/3", (k, 1), bn)
+    model = G.concatenate([path_a_model, path_b_model], name=name + "/final/concat")
+    model = G.conv2d(model, filters, 1, 1, "same", name=name + "/final/1x1")
+    return G.add([gen, model], name=name + "/final/add")
+
+
+def make_upscaler_incep_resnet(output_image_shape, filters=64, upscale_factor=4,
+                               a_block_type="3path", a_block_num=5, a_block_kernel=3,
+                               b_block_type="2path", b_block_num=10, b_block_kernel=7,
+                               c_block_type="2path", c_block_num=5, c_block_kernel=3, seed=7):
+    """model.py:443-497.  Kernels instantiated: 1x1, 3x3 / 5x5 (3-path blocks), 1xk / kx1 with k in 3, 5, 7 (2-path blocks)."""
+    input_image_shape = (output_image_shape[0] // upscale_factor, output_image_shape[1] // upscale_factor, output_image_shape[2])
+    upscale_times = int(math.log(upscale_factor, 2))
+    upscaler_input = G.Input(shape=input_image_shape, name="initial/input")
+    model = G.conv2d(upscaler_input, filters, 9, 1, "same", name="initial/conv/9x9")
+    upsc_model = model
+    for tag, btype, num, kern in (("A", a_block_type, a_block_num, a_block_kernel), ("B", b_block_type, b_block_num, b_block_kernel),
+                                  ("c", c_block_type, c_block_num, c_block_kernel)):            # 'c' in lower case: model.py:479,481
+        for index in range(num):
+            if btype == "3path":
+                model = inception_resblock_3path(model, filters, "inc_res_block/%s/3p/%d" % (tag, index), kernel_size=kern, batch_normalisation=True)
+            elif btype == "2path":
+                model = inception_resblock_2path(model, filters, "inc_res_block/%s/2p/%d" % (tag, index), kernel_size=kern, batch_normalisation=True)
+    model = G.conv2d(model, filters, c_block_kernel, 1, "same", name="prefinal/conv2d")
+    model = G.batch_norm(model, name="prefinal/batch_norm")
+    model = G.add([upsc_model, model], name="prefinal/tanh")
+    for index in range(upscale_times):
+        model = G.upsampling_block(model, c_block_kernel, 256, 2, name="upscaling/" + str(index) + "/block")
+    model = G.conv2d(model, 3, 9, 1, "same", activation="tanh", name="final/conv")
+    return G.build_model(upscaler_input, model, name="upscaler_incep_resnet", seed=seed)

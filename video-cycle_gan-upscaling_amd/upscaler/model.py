@@ -1207,6 +1207,7 @@ from ._graph import (Input, activation, add, atanh_scaled, batch_norm, batch_nor
                      make_upscaler_orig_functional, multiply_sigmoid, prelu, residual_block, residual_block_attention, resize_images,
                      upsampling_block, upsampling_block_attention)
 # the other generators train_gan3.py offers behind -gm (model.py:332-363, 505-827) -- see _generators.py
-from ._generators import (concatenate_layers, downsampling_unetish_block, find_crop_shape, make_upscaler_skip_con,  # noqa: E402,F401
+from ._generators import (concatenate_layers, downsampling_unetish_block, find_crop_shape, inception_mini_resblock,  # noqa: E402,F401
+                          inception_resblock_2path, inception_resblock_3path, make_upscaler_incep_resnet, make_upscaler_skip_con,
                           make_upscaler_unetish, make_upscaler_unetish_add, make_upscaler_unetish_complex, same_size_unetish_block,
                           sum_layers, upsampling_unetish_block)
