@@ -56,25 +56,121 @@ def conv2d(x, w_hwio, b, stride=1, padding="same"):
     return _conv2d_banded(x, w, b, stride)
 
 
+_BAND_BYTES = 1 << 23        # im2col buffer per band: cache-sized (64 MB bands: 1.4x slower, page faults on every fresh buffer)
+_POOL = None
+
+
+def _pool():
+    """im2col / col2im of doubles are single-threaded in torch: the bands of a convolution run on a few threads (the ops release the GIL)"""
+    global _POOL
+    if _POOL is None:
+        import os
+        from concurrent.futures import ThreadPoolExecutor
+        _POOL = ThreadPoolExecutor(max_workers=max(1, min(8, (os.cpu_count() or 2) // 2)))
+    return _POOL
+
+
+class _ConvGemmF64(torch.autograd.Function):
+    """float64 convolution of an already padded input as im2col + dgemm, in bands of output rows.
+
+    torch's own float64 CPU convolution is the same arithmetic through a slow path (no oneDNN for doubles: measured 7x slower than
+    unfold + matmul on this build) and materialises the whole n*cin*kh*kw*oh*ow buffer (87 GB for final/conv at 512x512, batch 2).
+    The bands are recomputed in the backward pass instead of being kept; partial results are summed in band order (deterministic)."""
+
+    @staticmethod
+    def _bands(x, kh, kw, stride):
+        n, cin, hp, wp = x.shape
+        oh, ow = (hp - kh) // stride + 1, (wp - kw) // stride + 1
+        per_row = cin * kh * kw * ow * 8
+        rows = max(1, min(oh, _BAND_BYTES // max(per_row, 1)))
+        return oh, ow, [(i, r0, min(r0 + rows, oh)) for i in range(n) for r0 in range(0, oh, rows)]
+
+    @staticmethod
+    def forward(ctx, x, w, stride):
+        o, cin, kh, kw = w.shape
+        oh, ow, bands = _ConvGemmF64._bands(x, kh, kw, stride)
+        wm = w.reshape(o, -1)
+        y = x.new_empty(x.shape[0], o, oh, ow)
+
+        @torch.no_grad()                     # grad mode is thread-local: the pool's threads do not inherit Function.forward's
+        def one(band):
+            i, r0, r1 = band
+            cols = F.unfold(x[i:i + 1, :, r0 * stride:(r1 - 1) * stride + kh], (kh, kw), stride=stride)[0]
+            y[i, :, r0:r1] = (wm @ cols).view(o, r1 - r0, ow)
+
+        list(_pool().map(one, bands))
+        ctx.save_for_backward(x, w)
+        ctx.stride = stride
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        stride = ctx.stride
+        o, cin, kh, kw = w.shape
+        oh, ow, bands = _ConvGemmF64._bands(x, kh, kw, stride)
+        wm = w.reshape(o, -1)
+        need_dx, need_dw = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+
+        @torch.no_grad()
+        def one(band):
+            i, r0, r1 = band
+            d = dy[i, :, r0:r1].reshape(o, -1)
+            lo, hi = r0 * stride, (r1 - 1) * stride + kh
+            pdw = d @ F.unfold(x[i:i + 1, :, lo:hi], (kh, kw), stride=stride)[0].t() if need_dw else None
+            pdx = F.fold((wm.t() @ d).unsqueeze(0), (hi - lo, x.shape[3]), (kh, kw), stride=stride) if need_dx else None
+            return pdw, pdx
+
+        dx = torch.zeros_like(x) if need_dx else None
+        dw = torch.zeros_like(wm) if need_dw else None
+        for (i, r0, r1), (pdw, pdx) in zip(bands, _pool().map(one, bands)):
+            if need_dw:
+                dw += pdw
+            if need_dx:
+                dx[i:i + 1, :, r0 * stride:(r1 - 1) * stride + kh] += pdx
+        return dx, (dw.view_as(w) if need_dw else None), None
+
+
 def _conv2d_banded(x, w, b, stride):
-    """F.conv2d on an already padded input.  torch evaluates float64 convolutions through an unfold buffer of
-    n*cin*kh*kw*oh*ow elements (87 GB for final/conv at 512x512, batch 2): such calls are cut into per-sample bands of
-    output rows (with their kh-1 halo rows) -- the same arithmetic, autograd included."""
-    n, cin, hp, wp = x.shape
-    kh, kw = w.shape[2], w.shape[3]
-    oh, ow = (hp - kh) // stride + 1, (wp - kw) // stride + 1
-    unfold_bytes = cin * kh * kw * oh * ow * x.element_size()
-    if x.dtype != torch.float64 or n * unfold_bytes <= (1 << 30):
+    """convolution of an already padded input: float64 through _ConvGemmF64, anything else through F.conv2d"""
+    if x.dtype != torch.float64:
         return F.conv2d(x, w, b, stride=stride)
-    rows = max(1, min(oh, int((1 << 30) // max(unfold_bytes // oh, 1))))
-    out = []
-    for i in range(n):
-        bands = []
-        for r0 in range(0, oh, rows):
-            r1 = min(r0 + rows, oh)
-            bands.append(F.conv2d(x[i:i + 1, :, r0 * stride:(r1 - 1) * stride + kh], w, b, stride=stride))
-        out.append(torch.cat(bands, 2))
-    return torch.cat(out, 0)
+    y = _ConvGemmF64.apply(x, w, stride)
+    return y if b is None else y + b.view(1, -1, 1, 1)
+
+
+class _ConvTGemmF64(torch.autograd.Function):
+    """float64 full transposed convolution (length (in-1)*s + k) as dgemm + col2im, per sample; w: (in, out, kh, kw)"""
+
+    @staticmethod
+    def forward(ctx, x, w, stride):
+        n, cin, h, wd = x.shape
+        _, o, kh, kw = w.shape
+        wm = w.reshape(cin, -1)                                    # [in, out*kh*kw]
+        size = ((h - 1) * stride + kh, (wd - 1) * stride + kw)
+        y = x.new_empty(n, o, *size)
+        for i in range(n):
+            y[i] = F.fold((wm.t() @ x[i].reshape(cin, -1)).unsqueeze(0), size, (kh, kw), stride=stride)[0]
+        ctx.save_for_backward(x, w)
+        ctx.stride = stride
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        stride = ctx.stride
+        n, cin, h, wd = x.shape
+        _, o, kh, kw = w.shape
+        wm = w.reshape(cin, -1)
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dw = torch.zeros_like(wm) if ctx.needs_input_grad[1] else None
+        for i in range(n):
+            dcols = F.unfold(dy[i:i + 1], (kh, kw), stride=stride)[0]          # [out*kh*kw, h*w]
+            if dx is not None:
+                dx[i] = (wm @ dcols).view(cin, h, wd)
+            if dw is not None:
+                dw += x[i].reshape(cin, -1) @ dcols.t()
+        return dx, (dw.view_as(w) if dw is not None else None), None
 
 
 def conv2d_transpose_same(x, w_hwoi, b, stride=2):
@@ -84,7 +180,7 @@ def conv2d_transpose_same(x, w_hwoi, b, stride=2):
     before = floor((k-s)/2), after = ceil((k-s)/2)  (SURVEY.md Appendix A)."""
     kh, kw = w_hwoi.shape[0], w_hwoi.shape[1]
     w = w_hwoi.permute(3, 2, 0, 1).contiguous()          # (in, out, kh, kw) == torch conv_transpose
-    full = F.conv_transpose2d(x, w, None, stride=stride)
+    full = _ConvTGemmF64.apply(x, w, stride) if x.dtype == torch.float64 else F.conv_transpose2d(x, w, None, stride=stride)
     oh, ow = x.shape[2] * stride, x.shape[3] * stride
     ct = max(kh - stride, 0) // 2
     cl = max(kw - stride, 0) // 2
