@@ -154,3 +154,38 @@ def test_dropout_masks_change_every_step_and_vanish_at_inference(rt):
     assert not G.dropout_masks(t0)
     a, b = G.predict(x.permute(0, 2, 3, 1).cpu().numpy()), G.predict(x.permute(0, 2, 3, 1).cpu().numpy())
     assert np.array_equal(a, b)
+
+
+def test_unetish_gan_step_graph_replay_matches_eager(rt):
+    """the three-call train step with a Dropout-bearing generator, eager against hipGraph replay: the keep-masks come from a
+    device-side step counter, so a recorded graph draws the same sequence of fresh masks as the eager loop -- bit for bit"""
+    from upscaler import _engine as E, model as PM
+    frames = [((np.random.RandomState(30 + i).randint(0, 256, (2, 32, 32, 3)) / 127.5 - 1).astype(np.float32),
+               (np.random.RandomState(40 + i).randint(0, 256, (2, 64, 64, 3)) / 127.5 - 1).astype(np.float32)) for i in range(4)]
+
+    def run(graph):
+        G = PM.make_upscaler_unetish((64, 64, 3), **U)
+        D = PM.make_discriminator_patchgan_70((64, 64, 3), seed=11)
+        opt = PM.Adam()
+        _, _, gan_train = PM.make_and_compile_gan2(G, D, (32, 32, 3), (64, 64, 3), "mse", 1.0, lambda: PM.WassersteinLosses(), 1e-2, optimizer=opt)
+        tr = gan_train.trainer
+        dev = [(E.to_device_nchw(rt, a), E.to_device_nchw(rt, b)) for a, b in frames]
+        out = []
+        if graph:
+            tr.capture_train_step(*dev[0])
+            for a, b in dev[1:]:
+                out.append(tr.train_step_graph(a, b))
+        else:
+            tr._t_dev = torch.tensor([opt.iterations, 0], dtype=torch.int32, device=rt.device)
+            tr.train_step(*dev[0])
+            for a, b in dev[1:]:
+                out.append(tr.train_step(a, b))
+        return out, G.get_weights_dict(), int(G._drop_step.item())
+
+    oe, ge, se = run(False)
+    og, gg, sg = run(True)
+    assert se == sg and se >= 4                                  # one mask draw per training forward of G, eager and replayed alike
+    for a, b in zip(oe, og):
+        assert a == b, (a, b)
+    assert all(np.array_equal(ge[k], gg[k]) for k in ge)
+    assert len({o[0] for o in oe}) == len(oe)                    # the steps differ (fresh frames, fresh masks)
