@@ -53,6 +53,14 @@ def main():
         print("%-28s B=%d  %.3f ms  %7.1f TFLOP/s (%.1f%% of %.0f)  %6.0f GB/s algorithmic (%.1f%% of %.0f)"
               % (name, B, ms, flop / ms / 1e9, 100 * flop / ms / 1e9 / PEAK_TF, PEAK_TF, nbytes / ms / 1e6,
                  100 * nbytes / ms / 1e6 / PEAK_GBS, PEAK_GBS), flush=True)
+    # the same launch on other operand statistics: the kernel is power-limited on random data, so its time follows the toggle rate
+    # of the operands, not its instruction stream
+    ep = L.EpilogueBf16(None, None, L.ACT_NONE, 0.0, None, None)
+    for name, xin in (("  .. input relu(randn)", torch.relu(x.float()).to(torch.bfloat16)), ("  .. input zeros", torch.zeros_like(x))):
+        def run():
+            L.check(rt.lib.vcg_conv2d_bf16_fwd(ctypes.byref(d), xin.data_ptr(), wk.data_ptr(), y.data_ptr(), ctypes.byref(ep), rt.stream), name)
+        ms = timeit(run)
+        print("%-28s B=%d  %.3f ms  %7.1f TFLOP/s" % (name, B, ms, flop / ms / 1e9), flush=True)
 
 
 def bench_convt(B):

@@ -53,7 +53,7 @@ def main():
     s = full[:, :, :4]
     tiles = B * (h // 16) * (w // 32) / 256.0
     per = s / tiles                                       # s_memtime ticks (100 MHz constant clock) per tile
-    names = ["mfma loop", "vmcnt wait", "barrier", "epilogue"]
+    names = ["phase A", "phase B", "vmcnt wait", "barrier"]   # A: half 0 + DMA of the next tile + drain of the previous half 1; B: half 1 + drain of half 0
     tot = per.sum(axis=2)
     print("variant %s, batch %d: %.1f tiles per workgroup; s_memtime ticks per tile (mean over 256 workgroups x 4 waves)" % (variant, B, tiles))
     for i, nm in enumerate(names):

@@ -340,16 +340,16 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_c64_bf16_kernel(C3Params p) {
 //   * a wave owns 32 of the 64 output channels x 8 of the 16 tile rows and keeps ITS 36 weight fragments (9 taps x 4
 //     channel groups) in 144 registers for the whole launch -- no weights in LDS at all;
 //   * LDS holds two 18x34-pixel halo tiles (2 x 76.5 KiB), filled by `buffer_load_dwordx4 ... lds` (range-checked by the
-//     buffer descriptor: the zero padding costs no branch and no select on data), issued two pieces per k-group under the
-//     MFMAs of the CURRENT tile;
-//   * for one (dx, channel group) the ten halo rows a wave needs are read ONCE and feed the MFMAs of all three dy:
-//     10 ds_read_b128 per 24 MFMAs (v1: 24), double-buffered in registers;
-//   * one barrier per tile; it orders LDS only, so the epilogue's stores drain under the next tile's MFMAs.
-// Measured (scripts/micro/v2_stamps.py, batch 32 at 256x256, sustained): 15.4 k cycles per tile = MFMA loop 72 % (11.1 k for
-// 9.2 k of MFMA issue), epilogue 26 %, barrier + wait 2 %; the matrix pipe is busy 60 % of the time (v1: 28 %) at the 1.63 GHz
-// the chip holds under this load (a bare v_mfma_f32_32x32x16_bf16 stream on random operands: 1.5-1.75 GHz, 1.5-1.75 PFLOP/s,
-// scripts/micro/mfma_peak_bf16.hip).  The variant WITH a residual input stays on v1: it moves 1.5x the bytes, and with
-// one wave per SIMD every stalled vector-memory issue also stalls that SIMD's MFMA stream (measured 0.234 ms against 0.213).
+//     buffer descriptor: the zero padding costs no branch and no select on data);
+//   * a software pipeline over HALF tiles (two accumulator sets of 4 rows): the epilogue of one half is issued in the MFMA
+//     shadow of the other, the next tile's DMA pieces in phase A's -- see the tile loop;
+//   * one barrier per tile; it orders LDS only, so the stores drain under the following MFMAs.
+// Measured (scripts/micro/v2_stamps.py, batch 32 at 256x256, sustained): 13.6 k cycles per tile for 9.2 k of MFMA issue
+// (serial epilogue: 15.4 k; v1's pipe is busy 28 % of the time) at the 1.6 GHz the chip holds under this load -- a bare
+// v_mfma_f32_32x32x16_bf16 stream on random operands holds 1.5-1.75 GHz = 1.5-1.75 PFLOP/s (scripts/micro/mfma_peak_bf16.hip):
+// the kernel is power-limited, and cycles saved come back as a lower clock.  The variant WITH a
+// residual input stays on v1: it moves 1.5x the bytes, and with one wave per SIMD every stalled vector-memory issue also
+// stalls that SIMD's MFMA stream (measured 0.234 ms against 0.213).
 constexpr int V2_TR = 16, V2_TC = 32, V2_HR = V2_TR + 2, V2_HC = V2_TC + 2;
 constexpr int V2_ROWB = V2_HC * 128;
 constexpr int V2_XB = V2_HR * V2_ROWB;                          // 78336
@@ -362,7 +362,9 @@ constexpr int V2_LDS = 2 * V2_BUF + PB;
 static_assert(V2_LDS <= 160 * 1024, "v2 trunk kernel: LDS");
 static_assert(V2_NDMA == 20 && V2_CHUNKS - 19 * V2_NT == 32, "v2 trunk kernel: DMA schedule");
 
-struct TilePos { int y0, x0; vcg_rsrc rs; };     // halo origin and image descriptor of a tile
+// (namespace scope: hipcc emits no host stub for a kernel template whose lambdas return a struct local to the kernel)
+struct TileSrc { unsigned base; int x0; vcg_rsrc rs; };          // a tile's halo: byte offset of its origin in the image, first column, image descriptor
+struct OutPos { vcg_rsrc rs; int gx, gy0; bool okx; };           // where a half's accumulators go: image descriptor, column, first row
 
 // Diagnostic build only (-DVCG_V2_STAMPS, scripts/micro/v2_stamps.sh): s_memtime brackets around the four segments of a
 // tile, summed per wave in scalar registers and written to a buffer of their own after the loop.  No stamp executes in
@@ -392,13 +394,6 @@ __global__ __launch_bounds__(V2_NT, 1) void conv3x3_c64_bf16_v2_kernel(C3Params 
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int coh = wv & 1, rg = wv >> 1;                       // channel half, row group (rows 8rg .. 8rg+7 of the tile)
 
-    // this wave's 36 weight fragments: A[row = co][k = 8hh + j] of (tap, channel group s) = packed [tap][co][ci] chunk 2s + hh
-    bf16x8 wa[36];
-#pragma unroll
-    for (int i = 0; i < 36; ++i) {
-        const int tap = i >> 2, s = i & 3;
-        wa[i] = __builtin_bit_cast(bf16x8, p.w[(tap * 64 + coh * 32 + r) * 8 + 2 * s + hh]);
-    }
     if (tid < 64) {
         prm[tid] = p.scale ? p.scale[tid] : 1.f;
         prm[64 + tid] = p.shift ? p.shift[tid] : 0.f;
@@ -414,172 +409,204 @@ __global__ __launch_bounds__(V2_NT, 1) void conv3x3_c64_bf16_v2_kernel(C3Params 
     }
     const long img_bytes = (long)p.h * p.w_ * 128;
 
-    // one 4-KiB piece (round k of 20) of a tile's halo: slot = 16-byte chunk of the LDS image, in image order
-    auto locate = [&](int tile) {
-        const int txi = tile % p.tiles_x, t2 = tile / p.tiles_x, tyi = t2 % p.tiles_y, img = t2 / p.tiles_y;
-        return TilePos{tyi * V2_TR - 1, txi * V2_TC - 1, make_rsrc((const unsigned char*)p.x + img * img_bytes, (unsigned long)img_bytes)};
-    };
-    // (row, col) of a lane's slot advance by 32 pixels per round: kept incrementally (dma_row, dma_col), restarted per tile
-    // from an opaque copy of the lane id -- otherwise hipcc precomputes all 20 rounds into 50 registers this kernel lacks
-    int dma_row = 0, dma_col = 0;
-    auto dma_begin = [&]() {
-        int t = tid;
-        asm volatile("" : "+v"(t));
-        dma_row = (t >> 3) / V2_HC;
-        dma_col = (t >> 3) - dma_row * V2_HC;
-    };
-    auto dma = [&](const TilePos& tp, int buf, int k, bool live) {
-        const int row = dma_row, col = dma_col;
-        dma_col += 32;
-        if (dma_col >= V2_HC) dma_col -= V2_HC, ++dma_row;
-        if (k == V2_NDMA - 1 && wv != 0) return;                 // wave-uniform
-        const int sl = k * V2_NT + tid;
+    // one 4-KiB piece (round k of 20) of a tile's halo: slot = 16-byte chunk of the LDS image, in image order.  Issued between MFMAs,
+    // so its address arithmetic has to fit an MFMA's shadow: per lane and round the byte offset of the slot's source RELATIVE to the
+    // tile's halo origin ((row * w + col) * 128 + chunk * 16) and its halo column are launch constants (20 + 5 registers); a piece is
+    // then  offset = tile base + constant,  one column test (left / right image edge)  and a select.  Rows above / below the image
+    // need no test: their offsets fall outside the image's buffer descriptor (negative ones wrap to > 4 GiB - 4 MiB); without a
+    // next tile the descriptor has zero records and every piece writes zeros into the idle buffer.
+    unsigned dma_c[V2_NDMA], dma_colp[(V2_NDMA + 3) / 4];
+#pragma unroll
+    for (int k = 0; k < V2_NDMA; ++k) {
+        const int sl = k * V2_NT + tid, P = sl >> 3, row = P / V2_HC, col = P - row * V2_HC;
         const int cs = (sl & 7) ^ ((col >> 1) & 7);                                // stored chunk (sl & 7) holds source chunk cs
-        const int gy = tp.y0 + row, gx = tp.x0 + col;
-        const bool ok = (unsigned)gy < (unsigned)p.h && (unsigned)gx < (unsigned)p.w_ && sl < V2_CHUNKS && live;
-        unsigned off = (unsigned)((gy * p.w_ + gx) * 128 + cs * 16);
+        dma_c[k] = (unsigned)((row * p.w_ + col) * 128 + cs * 16);
+        if ((k & 3) == 0) dma_colp[k >> 2] = 0;
+        dma_colp[k >> 2] |= (unsigned)(sl < V2_CHUNKS ? col : 255) << (8 * (k & 3));     // 255: the slots past the tile (round 19, lanes 32-63)
+    }
+    auto locate = [&](int tile, bool live) {
+        const int txi = tile % p.tiles_x, t2 = tile / p.tiles_x, tyi = t2 % p.tiles_y, img = t2 / p.tiles_y;
+        const int y0 = tyi * V2_TR - 1, x0 = txi * V2_TC - 1;
+        return TileSrc{(unsigned)((y0 * p.w_ + x0) * 128), x0, make_rsrc((const unsigned char*)p.x + img * img_bytes, (unsigned long)(live ? img_bytes : 0))};
+    };
+    auto dma = [&](const TileSrc& ts, int buf, int k) {
+        if (k == V2_NDMA - 1 && wv != 0) return;                 // wave-uniform
+        const int col = (int)((dma_colp[k >> 2] >> (8 * (k & 3))) & 255u);
+        unsigned off = ts.base + dma_c[k];
         asm volatile("" : "+v"(off));                            // a select, not a branch around the arithmetic (it would split the schedule)
-        off = ok ? off : VCG_OOB;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(tp.rs, (void __attribute__((address_space(3)))*)(smem + buf * V2_BUF + (k * V2_NT + wv * 64) * 16),
+        off = (unsigned)(ts.x0 + col) < (unsigned)p.w_ ? off : VCG_OOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ts.rs, (void __attribute__((address_space(3)))*)(smem + buf * V2_BUF + (k * V2_NT + wv * 64) * 16),
                                                  16, off, 0, 0, 0);
     };
 
-    bf16x8 fb[2][10];
-    auto frag = [&](const unsigned char* xb, int g, int b) {
-        const int dx = g >> 2, s = g & 3;
-#pragma unroll
-        for (int j = 0; j < 10; ++j) fb[b][j] = *(const bf16x8*)(xb + j * V2_ROWB + (boff[dx] ^ (s << 5)));
-    };
-
+    // the first tile's halo goes out before anything else (it is the HBM round trip every workgroup starts with), the weights behind it
     int tile = blockIdx.x, buf = 0;
     if (tile < p.total) {
-        const TilePos tp = locate(tile);
-        dma_begin();
+        const TileSrc tp = locate(tile, true);
 #pragma unroll
-        for (int k = 0; k < V2_NDMA; ++k) dma(tp, 0, k, true);
+        for (int k = 0; k < V2_NDMA; ++k) dma(tp, 0, k);
     }
-    __builtin_amdgcn_s_waitcnt(0x0F70);                          // vmcnt(0): this wave's pieces have landed
+    // this wave's 36 weight fragments: A[row = co][k = 8hh + j] of (tap, channel group s) = packed [tap][co][ci] chunk 2s + hh
+    bf16x8 wa[36];
+#pragma unroll
+    for (int i = 0; i < 36; ++i) {
+        const int tap = i >> 2, s = i & 3;
+        wa[i] = __builtin_bit_cast(bf16x8, p.w[(tap * 64 + coh * 32 + r) * 8 + 2 * s + hh]);
+    }
+
+    // ---- the pipelined tile loop ---------------------------------------------------------------------------------------
+    // A wave's 8 rows are two HALVES of 4 rows with an accumulator set each (2 x 64 registers): while the 144 MFMAs of one half
+    // run, the epilogue of the OTHER half (finished 144 MFMAs ago) is issued between them, one 16-byte store unit (8 channels of
+    // one row) per k-group -- with one wave per SIMD nothing else could fill the MFMA shadow, and a serial epilogue was 26 % of
+    // the tile (profiles/r02_v2_stamps.txt).  Phase A of a tile computes half 0 and drains half 1 of the PREVIOUS tile (whose
+    // position is carried in `pv`); phase B computes half 1 and drains half 0.  Per (dx, channel group) a half reads its six halo
+    // rows once for the MFMAs of all three dy.
+    bf16x8 fb[2][6];
+    auto frag = [&](const unsigned char* xb, int h, int g, int b) {
+        const int dx = g >> 2, s = g & 3;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) fb[b][j] = *(const bf16x8*)(xb + (4 * h + j) * V2_ROWB + (boff[dx] ^ (s << 5)));
+    };
+    auto out_off = [&](const OutPos& o, int n, int q) {
+        const int gy = o.gy0 + n;
+        unsigned off = (unsigned)((gy * p.w_ + o.gx) * 128 + (coh * 32 + 16 * q + 8 * hh) * 2);
+        asm volatile("" : "+v"(off));                            // a select, not a branch around the arithmetic (it would split the schedule)
+        return gy < p.h && o.okx ? off : VCG_OOB;
+    };
+    // one store unit u = (q, n): channels 16q + 8hh + {0..7} of row n.  An MFMA tile leaves lane (pixel, h) with channels
+    // 8g+4h+{0..3}; v_permlane32_swap between the register groups (2q, 2q+1) of the two half-waves makes them 8 consecutive ones.
+    float sc[8], sh[8], al[8];
+    auto epi_params = [&](int q) {
+        int prm_o = 0;
+        asm volatile("" : "+v"(prm_o));                  // re-read per use: 24 registers not to be held across tiles
+        const float* prm_t = prm + prm_o + coh * 32 + 16 * q + 8 * hh;
+        if (AFF) {
+            *(f32x4*)&sc[0] = *(const f32x4*)(prm_t);
+            *(f32x4*)&sc[4] = *(const f32x4*)(prm_t + 4);
+            *(f32x4*)&sh[0] = *(const f32x4*)(prm_t + 64);
+            *(f32x4*)&sh[4] = *(const f32x4*)(prm_t + 68);
+        }
+        if (SLOPE) {
+            *(f32x4*)&al[0] = *(const f32x4*)(prm_t + 128);
+            *(f32x4*)&al[4] = *(const f32x4*)(prm_t + 132);
+        }
+    };
+    // the unit in seven stages, so that a stage fits the shadow of one MFMA (32 cycles = about seven VALU instructions):
+    //   0, 1: accumulator reads + permlane swaps of channels 0-3 / 4-7;  2..5: scale / shift / slope of two values each;  6: pack + store
+    float ev[8];
+    auto epi_stage = [&](f32x16 (&acc)[4], const OutPos& o, int u, int st) {
+        const int q = u >> 2, n = u & 3;
+        if (st == 0 && n == 0) epi_params(q);
+        if (st < 2) {
+#pragma unroll
+            for (int j = 2 * st; j < 2 * st + 2; ++j) {
+                float lo = acc[n][8 * q + j], hi = acc[n][8 * q + 4 + j];
+                swap32(lo, hi);
+                ev[j] = lo;
+                ev[4 + j] = hi;
+            }
+            // pin the stage where it is written: LLVM sinks side-effect-free arithmetic across sched_barrier down to its use
+            asm volatile("" : "+v"(ev[2 * st]), "+v"(ev[2 * st + 1]), "+v"(ev[2 * st + 4]), "+v"(ev[2 * st + 5]));
+        } else if (st < 6) {
+#pragma unroll
+            for (int j = 2 * (st - 2); j < 2 * (st - 2) + 2; ++j) {
+                float t = ev[j];
+                if (AFF) t = t * sc[j] + sh[j];
+                if (SLOPE) t = t >= 0.f ? t : t * al[j];
+                ev[j] = t;
+            }
+            asm volatile("" : "+v"(ev[2 * (st - 2)]), "+v"(ev[2 * (st - 2) + 1]));
+        } else {
+            bf16x8 ov;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ov[j] = (__bf16)ev[j];
+            // through the image's buffer descriptor: an out-of-image lane (or a half with nothing pending) gets the out-of-range
+            // offset instead of an exec mask -- no branch to split the schedule, and hipcc can count the stores in its vmcnt waits
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ov), o.rs, (int)out_off(o, n, q), 0, 0);
+        }
+    };
+    // one phase: 12 k-groups of 12 MFMAs into `acc` (rows 4h..4h+3), the next group's six rows read under them, `drain`'s eight
+    // store units in groups 2..9, and (phase A only) two DMA pieces of the next tile in groups 0..9.  The order inside a group is
+    // written out and pinned (sched_barrier after every MFMA): left to the scheduler, the drain ends up behind the MFMAs.
+    auto phase = [&](f32x16 (&acc)[4], f32x16 (&drain)[4], const OutPos& dpos, const unsigned char* xb, int h, const TileSrc& np, int nbuf,
+                     bool has_next) {
+        (void)has_next;
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[n][e] = 0.f;
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int g = 0; g < 12; ++g) {
+            const int cur = g & 1, dx = g >> 2, s = g & 3;
+            const bool dr = g >= 2 && g < 10, dm = h == 0 && g < 10;
+#pragma unroll
+            for (int i = 0; i < 12; ++i) {
+                const int dy = i >> 2, n = i & 3;
+                acc[n] = mfma_bf16(wa[(dy * 3 + dx) * 4 + s], fb[cur][n + dy], acc[n]);
+                if (i == 0) {
+                    if (g + 1 < 12) frag(xb, h, g + 1, cur ^ 1);
+                    else if (h == 0) frag(xb, 1, 0, cur ^ 1);         // phase B's first rows, under phase A's last group
+                }
+                // unconditional DMA (no branch to split the group): without a next tile its descriptor has no records
+                if (i == 1 && dm) dma(np, nbuf, 2 * g);
+                if (i == 3 && dm) dma(np, nbuf, 2 * g + 1);
+                if (dr && i == 2) epi_stage(drain, dpos, g - 2, 0);
+                if (dr && i >= 4 && i <= 9) epi_stage(drain, dpos, g - 2, i - 3);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+
+    __builtin_amdgcn_s_waitcnt(0x0F70);                          // vmcnt(0): this wave's pieces (and weights) have landed
     lds_barrier();
-    if (tile < p.total) frag(smem, 0, 0);
-    unsigned long long st0 = 0, st1 = 0, st2 = 0, st3 = 0, st4 = 0, sum_mfma = 0, sum_wait = 0, sum_bar = 0, sum_epi = 0;
-    (void)st0, (void)st1, (void)st2, (void)st3, (void)st4, (void)sum_mfma, (void)sum_wait, (void)sum_bar, (void)sum_epi;
+    unsigned long long st0 = 0, st1 = 0, st2 = 0, st3 = 0, st4 = 0, sum_pa = 0, sum_pb = 0, sum_wt = 0, sum_br = 0;
+    (void)st0, (void)st1, (void)st2, (void)st3, (void)st4, (void)sum_pa, (void)sum_pb, (void)sum_wt, (void)sum_br;
+
+    f32x16 acc0[4], acc1[4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc1[n][e] = 0.f;
+    OutPos pv{make_rsrc(p.y, 0), 0, 0, false};                   // nothing pending before the first tile: every offset out of range
 
     for (; tile < p.total; tile += gridDim.x, buf ^= 1) {
         V2_STAMP(st0);
         const int next = tile + gridDim.x;
         const bool has_next = next < p.total;
-        const TilePos np = locate(has_next ? next : tile);
+        const TileSrc np = locate(has_next ? next : tile, has_next);
         const unsigned char* xb = smem + buf * V2_BUF;
         const int txi = tile % p.tiles_x, t2 = tile / p.tiles_x, tyi = t2 % p.tiles_y, img = t2 / p.tiles_y;
-        const int gx = txi * V2_TC + r, gy0 = tyi * V2_TR + rg * 8;
-        const bool okx = gx < p.w_;
-
-        f32x16 acc[8];
-#pragma unroll
-        for (int n = 0; n < 8; ++n)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[n][e] = 0.f;
-
-        // 12 k-groups (dx, s): ten halo rows -> 24 MFMAs (3 dy x 8 rows); group g+1's rows are read under group g's MFMAs
-        dma_begin();
-        // output stores go through a per-image buffer descriptor: an out-of-image lane gets the out-of-range offset instead
-        // of an exec mask (no branch around the store, and hipcc can count the stores in its vmcnt waits)
+        const int gx = txi * V2_TC + r;
         const vcg_rsrc yrs = make_rsrc((const unsigned char*)p.y + img * img_bytes, (unsigned long)img_bytes);
-        auto out_off = [&](int n, int q) {
-            const int gy = gy0 + n;
-            return gy < p.h && okx ? (unsigned)((gy * p.w_ + gx) * 128 + (coh * 32 + 16 * q + 8 * hh) * 2) : VCG_OOB;
-        };
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int g = 0; g < 12; ++g) {
-            const int cur = g & 1, dx = g >> 2, s = g & 3;
-            if (g + 1 < 12) frag(xb, g + 1, cur ^ 1);
-            if (g < 10) {
-                // unconditional (no branch to split the group's schedule): without a next tile the pieces are zeros into the idle buffer
-                dma(np, buf ^ 1, 2 * g, has_next);
-                dma(np, buf ^ 1, 2 * g + 1, has_next);
-            }
-#pragma unroll
-            for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-                for (int n = 0; n < 8; ++n) acc[n] = mfma_bf16(wa[(dy * 3 + dx) * 4 + s], fb[cur][n + dy], acc[n]);
-            if (g + 1 < 12) {
-                // 2 MFMAs, then one of the next group's reads, ten times; everything else of the group floats between them
-#pragma unroll
-                for (int j = 0; j < 10; ++j) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        // The next tile's pieces were issued at least two k-groups ago: retire them, then the one barrier of the tile: every
-        // wave's pieces are in LDS and every wave is done reading this tile's image.  The epilogue comes AFTER it, so the
-        // waves drift apart there and the stores drain under the next tile's MFMAs.
+        const OutPos p0{yrs, gx, tyi * V2_TR + rg * 8, gx < p.w_}, p1{yrs, gx, tyi * V2_TR + rg * 8 + 4, gx < p.w_};
+        frag(xb, 0, 0, 0);
+        phase(acc0, acc1, pv, xb, 0, np, buf ^ 1, has_next);      // half 0; drains the previous tile's half 1
         V2_STAMP(st1);
-        __builtin_amdgcn_s_waitcnt(0x0F70);
+        phase(acc1, acc0, p0, xb, 1, np, buf ^ 1, has_next);      // half 1; drains this tile's half 0
+        pv = p1;
         V2_STAMP(st2);
-        lds_barrier();
+        // The next tile's pieces were issued in phase A: retire them -- vmcnt(8) leaves phase B's eight younger stores in flight
+        // (vector memory operations retire in order) -- then the one barrier of the tile: every wave's pieces are in LDS and
+        // every wave is done reading this tile's image.
+        __builtin_amdgcn_s_waitcnt(0x0F78);
         V2_STAMP(st3);
-        __builtin_amdgcn_sched_barrier(0);
-
-        // epilogue: y = act(acc * scale + shift) -> bf16.  An MFMA tile leaves lane (pixel, h) with channels 8g+4h+{0..3};
-        // v_permlane32_swap between the register groups (2q, 2q+1) of the two half-waves turns that into 8 consecutive
-        // channels 16q+8h+{0..7}: 16-byte stores.
-        int prm_o = 0;
-        asm volatile("" : "+v"(prm_o));                  // re-read the parameters per tile: 48 registers not to be held across the MFMAs
-        const float* prm_t = prm + prm_o;
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            if (q == 1) {
-                // the next tile's first rows, read under the second half of the epilogue
-                __builtin_amdgcn_sched_barrier(0);
-                if (has_next) frag(smem + (buf ^ 1) * V2_BUF, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            const int co = coh * 32 + 16 * q + 8 * hh;
-            float sc[8], sh[8], al[8];
-            if (AFF) {
-                *(f32x4*)&sc[0] = *(const f32x4*)(prm_t + co);
-                *(f32x4*)&sc[4] = *(const f32x4*)(prm_t + co + 4);
-                *(f32x4*)&sh[0] = *(const f32x4*)(prm_t + 64 + co);
-                *(f32x4*)&sh[4] = *(const f32x4*)(prm_t + 64 + co + 4);
-            }
-            if (SLOPE) {
-                *(f32x4*)&al[0] = *(const f32x4*)(prm_t + 128 + co);
-                *(f32x4*)&al[4] = *(const f32x4*)(prm_t + 128 + co + 4);
-            }
-#pragma unroll
-            for (int n = 0; n < 8; ++n) {
-                float v[8];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    float lo = acc[n][8 * q + j], hi = acc[n][8 * q + 4 + j];
-                    swap32(lo, hi);
-                    v[j] = lo;
-                    v[4 + j] = hi;
-                }
-                bf16x8 ov;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    float u = v[j];
-                    if (AFF) u = u * sc[j] + sh[j];
-                    if (SLOPE) u = u >= 0.f ? u : u * al[j];
-                    ov[j] = (__bf16)u;
-                }
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ov), yrs, (int)out_off(n, q), 0, 0);
-            }
-        }
+        lds_barrier();
         V2_STAMP(st4);
-        V2_STAMP_ADD(sum_mfma, st0, st1);
-        V2_STAMP_ADD(sum_wait, st1, st2);
-        V2_STAMP_ADD(sum_bar, st2, st3);
-        V2_STAMP_ADD(sum_epi, st3, st4);
+        V2_STAMP_ADD(sum_pa, st0, st1);
+        V2_STAMP_ADD(sum_pb, st1, st2);
+        V2_STAMP_ADD(sum_wt, st2, st3);
+        V2_STAMP_ADD(sum_br, st3, st4);
     }
+    // the last tile's half 1
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int st = 0; st < 7; ++st) epi_stage(acc1, pv, u, st);
 #ifdef VCG_V2_STAMPS
     if (lane == 0) {
         unsigned long long* o = vcg_v2_stamp_sums + (blockIdx.x * 4 + wv) * 6;
-        o[0] = sum_mfma, o[1] = sum_wait, o[2] = sum_bar, o[3] = sum_epi;
+        o[0] = sum_pa, o[1] = sum_pb, o[2] = sum_wt, o[3] = sum_br;
         o[4] = __builtin_amdgcn_s_memtime() - k_c0, o[5] = __builtin_amdgcn_s_memrealtime() - k_r0;     // whole kernel: core clock / 100 MHz
     }
 #endif
@@ -1409,7 +1436,7 @@ int vcg_conv9x9_to3_bf16_dgrad(const vcg_conv_desc* d, const void* dy, const voi
 }  // extern "C"
 
 #ifdef VCG_V2_STAMPS
-// diagnostic build only: copy the per-wave sums [256 workgroups][4 waves][mfma, wait, barrier, epilogue, kernel core clocks, kernel 100-MHz ticks] to the host
+// diagnostic build only: copy the per-wave sums [256 workgroups][4 waves][phase A, phase B, vmcnt wait, barrier, kernel core clocks, kernel 100-MHz ticks] to the host
 extern "C" int vcg_debug_v2_stamps(unsigned long long* host_out) {
     if (hipDeviceSynchronize() != hipSuccess) return -1;
     return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(vcg_v2_stamp_sums), sizeof(unsigned long long) * 256 * 4 * 6);
