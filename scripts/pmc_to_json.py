@@ -43,7 +43,7 @@ def main():
             continue
         if "FETCH_SIZE" not in cs or "WRITE_SIZE" not in cs:
             continue
-        base = n.split("<")[0] if n.startswith(("conv3x3_c64_bf16", "wgrad3x3_c64_bf16")) else n
+        base = n.split("<")[0] if n.startswith(("conv3x3_c64_bf16", "wgrad3x3_c64_bf16")) else n      # ..._bf16_kernel (v1) / ..._bf16_v2_kernel
         rec = {"kernel": base, "variant": n, "shape": shape, "fetch_bytes": int(2 * 1024 * sum(cs["FETCH_SIZE"]) / len(cs["FETCH_SIZE"])),
                "write_bytes": int(1024 * sum(cs["WRITE_SIZE"]) / len(cs["WRITE_SIZE"])), "dispatches": len(cs["FETCH_SIZE"]),
                "mean_us_under_pmc": round(sum(dur[n]) / len(dur[n]), 1), "source": source}
