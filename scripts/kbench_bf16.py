@@ -126,8 +126,43 @@ def bench_wgrad(B):
                  100 * nbytes / ms / 1e6 / PEAK_GBS, PEAK_GBS), flush=True)
 
 
+def bench_norm(B):
+    """BatchNormalization + PReLU of a residual block on bf16 NHWC: statistics pass, apply pass, backward (two reduction passes + apply)"""
+    rt = E.Runtime.get()
+    dev = rt.device
+    h = w = 256
+    n_el = B * h * w * 64
+    x = torch.randn(B, h, w, 64, device=dev).to(torch.bfloat16)
+    dy = torch.randn(B, h, w, 64, device=dev).to(torch.bfloat16)
+    y, dx = torch.empty_like(x), torch.empty_like(x)
+    mean, var = torch.empty(64, device=dev), torch.empty(64, device=dev)
+    inv = torch.rand(64, device=dev) + 0.5
+    ga, be, al = torch.rand(64, device=dev) + 0.5, torch.rand(64, device=dev) - 0.5, torch.rand(64, device=dev) * 0.3
+    dg, db, da = torch.empty(64, device=dev), torch.empty(64, device=dev), torch.empty(64, device=dev)
+    ws, wsn = rt.workspace(max(rt.lib.vcg_norm_stats_bf16_workspace_bytes(B, 64, h * w, L.NORM_BATCH),
+                               rt.lib.vcg_norm_act_bwd_bf16_workspace_bytes(B, 64, h * w, L.NORM_BATCH)))
+
+    def stats():
+        L.check(rt.lib.vcg_norm_stats_bf16(x.data_ptr(), B, 64, h * w, L.NORM_BATCH, mean.data_ptr(), var.data_ptr(), ws, wsn, rt.stream), "stats")
+
+    def fwd():
+        L.check(rt.lib.vcg_norm_act_fwd_bf16(x.data_ptr(), B, 64, h * w, ga.data_ptr(), be.data_ptr(), 0, L.ACT_PRELU, 0.0, al.data_ptr(), None,
+                                             y.data_ptr(), rt.stream), "fwd")
+
+    def bwd():
+        L.check(rt.lib.vcg_norm_act_bwd_bf16(x.data_ptr(), dy.data_ptr(), B, 64, h * w, L.NORM_BATCH, mean.data_ptr(), inv.data_ptr(), ga.data_ptr(),
+                                             be.data_ptr(), L.ACT_PRELU, 0.0, al.data_ptr(), 1, dx.data_ptr(), dg.data_ptr(), db.data_ptr(),
+                                             da.data_ptr(), ws, wsn, rt.stream), "bwd")
+    stats()
+    for name, fn, passes in (("BN statistics (1 read)", stats, 1), ("BN + PReLU apply (r + w)", fwd, 2), ("BN + PReLU backward (2r + 2r + w)", bwd, 5)):
+        ms = timeit(fn)
+        print("%-34s B=%d  %.3f ms  %6.0f GB/s algorithmic (%.1f%% of %.0f)" % (name, B, ms, passes * n_el * 2 / ms / 1e6,
+                                                                                100 * passes * n_el * 2 / ms / 1e6 / PEAK_GBS, PEAK_GBS), flush=True)
+
+
 if __name__ == "__main__":
     main()
+    bench_norm(int(sys.argv[1]) if len(sys.argv) > 1 else 32)
     bench_convt(int(sys.argv[1]) if len(sys.argv) > 1 else 32)
     bench_final(int(sys.argv[1]) if len(sys.argv) > 1 else 32)
     bench_wgrad(int(sys.argv[1]) if len(sys.argv) > 1 else 32)
