@@ -34,15 +34,20 @@ def main():
              ("pg4 4x4s1 256->512 @64", 256, 512, 4, 1, 1, 64), ("s2 3x3s2 64->128 @512", 64, 128, 3, 2, "same", 512),
              ("s3 3x3s2 128->256 @256", 128, 256, 3, 2, "same", 256), ("s4 3x3s2 256->512 @128", 256, 512, 3, 2, "same", 128),
              ("s5 3x3s2 512->512 @64", 512, 512, 3, 2, "same", 64)]
+    if len(sys.argv) > 1 and sys.argv[1] == "c4":       # the PatchGAN layers at config C4's frames (1080x1920, batch 4): not L2-resident
+        B = 4
+        cases = [("pg2 4x4s2 64->128 @540x960", 64, 128, 4, 2, 1, (540, 960)), ("pg3 4x4s2 128->256 @270x480", 128, 256, 4, 2, 1, (270, 480)),
+                 ("pg4 4x4s1 256->512 @135x240", 256, 512, 4, 1, 1, (135, 240))]
     print("%-26s %18s %18s %18s   (ms / TFLOP/s / %% of %.0f)" % ("case", "fwd", "dgrad", "wgrad", PEAK))
     for name, cin, cout, k, s, pad, hw in cases:
+        hw, ww = hw if isinstance(hw, tuple) else (hw, hw)
         layer = E.Conv2DBf16("c", cin, cout, k, s, pad)
         ps = E.ParamStore()
         layer.declare(ps)
         ps.materialize(rt)
         layer.bind(rt, ps)
         ps.set_weights(layer.init_weights(np.random.RandomState(0)))
-        x = torch.randn(B, hw, hw, cin, device=rt.device).to(torch.bfloat16)
+        x = torch.randn(B, hw, ww, cin, device=rt.device).to(torch.bfloat16)
         y, ctx = layer.forward(x)
         dy = torch.randn_like(y)
         flop = 2.0 * (y.numel() // cout) * cin * cout * k * k

@@ -582,6 +582,12 @@ GCONV_CASES = [
     (512, 512, 3, 2, "same", 3, 2, 2),         # 2x2 -> 1x1
     (64, 64, 3, 1, "same", 1, 9, 20),
     (64, 128, 4, 2, 1, 3, 70, 38),             # many tiles, several images
+    # large enough for the LDS-tiled kernel (unit input stride, >= 64 (tile, 128-channel group) pairs): forward of stride-1 layers,
+    # data gradients of any stride
+    (256, 512, 4, 1, 1, 2, 70, 50),            # PatchGAN block 4: forward (4x4 box of taps) and data gradient on the LDS kernel, ragged tiles
+    (64, 128, 3, 1, "same", 4, 64, 64),        # forward on the LDS kernel (3x3 box)
+    (128, 256, 4, 2, 1, 4, 128, 128),          # data gradient of a stride-2 layer: four phases of 2x2 taps
+    (256, 256, 3, 2, "same", 8, 64, 61),       # 3x3 stride 2: phases with one or two taps per dimension (absent offsets in the box), ragged
 ]
 
 

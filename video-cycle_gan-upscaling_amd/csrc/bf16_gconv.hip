@@ -56,7 +56,7 @@ __device__ __forceinline__ bf16x8 ld_frag(vcg_rsrc r, unsigned off) {
 
 // workgroup = 4 waves; wave = 64 output channels (2 MFMA row blocks) x NT tiles of 32 consecutive logical pixels
 template <int NT>
-__global__ __launch_bounds__(256, (NT == 4 ? 2 : 3)) void gconv_bf16_kernel(const GcParams p) {
+__global__ __launch_bounds__(256, (NT == 4 ? 2 : 4)) void gconv_bf16_kernel(const GcParams p) {
     const int lane = threadIdx.x & 63, r = lane & 31, hh = lane >> 5;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int mb0 = blockIdx.y * 2;                                     // first 32-row block of this workgroup
@@ -171,6 +171,191 @@ __global__ __launch_bounds__(256, (NT == 4 ? 2 : 3)) void gconv_bf16_kernel(cons
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// LDS-tiled variant for unit input stride (every stride-1 forward convolution and EVERY data gradient: a phase of a strided
+// layer's gradient reads dy at unit stride), 64-channel input chunks, 128 output channels per workgroup
+// ---------------------------------------------------------------------------------------------------------------
+// The streaming kernel above asks the vector L1 for 32 different 128-byte lines per operand load (one per pixel, 32 bytes of
+// each used) and re-asks for every tap: at the discriminators' 256->512 layer it runs at 220-270 TFLOP/s whatever its
+// occupancy (scripts/kbench_gconv.py).  Here a workgroup stages the (8+SP) x (32+SP)-pixel halo of one 64-channel chunk in LDS
+// by `buffer_load ... lds` (whole 128-byte lines, 1 KiB per instruction, zero padding by the range check), double-buffered
+// over the (tile, chunk) sequence it walks, and reads it the way the trunk kernel does: XOR-swizzled 16-byte fragments, the
+// rows of one (dx, channel group) read once for all dy.  Wave w owns 32 of the workgroup's 128 output channels x the tile's
+// 8 rows (128 accumulator registers); its weight fragments stream from L1/L2 as in the kernel above (one coalesced 1-KiB load
+// per 8 MFMAs), requested one k-group ahead.  One LDS-only barrier per chunk.
+constexpr int GL_TR = 8, GL_TC = 32;
+
+struct GlParams {
+    const void* x;          // bf16 NHWC [n][ih][iw][kch]
+    const void* wf;         // fragments [wt][kch/16][mblocks][64 lanes] x 16 bytes
+    void* y;                // bf16 NHWC [n][oh][ow][mch]
+    const float* bias;
+    const void* mask_src;
+    size_t wbytes;
+    int n, ih, iw, kch, oh, ow, mch, loh, low, osy, osx, ooy, oox, mblocks, act;
+    float alpha, mask_slope;
+    int dy0, dx0;           // smallest tap offsets: halo origin of a tile = (ly0 + dy0, lx0 + dx0)
+    int tiles_x, tiles_y, pairs, mgroups;
+    short wt[25];           // weight tap of offset (dyo, dxo) from the halo origin, row-major (SP+1)^2, or -1
+};
+
+struct GlSrc { int img, y0, x0, mg, ty, tx; };       // a (tile, output-channel group) pair: image, halo origin, group, tile coordinates
+
+__device__ __forceinline__ void gl_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+template <int SP>
+__global__ __launch_bounds__(256, 1) void gconv_lds_bf16_kernel(const GlParams p) {
+    constexpr int HR = GL_TR + SP, HC = GL_TC + SP, ROWB = HC * 128, XB = HR * ROWB, CH16 = XB / 16;
+    constexpr int NDMA = (CH16 + 255) / 256, BUF = NDMA * 4096, G = (SP + 1) * 4;
+    static_assert(2 * BUF <= 160 * 1024, "gconv_lds: LDS");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, hh = lane >> 5;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nchunk = p.kch >> 6, ksteps = p.kch >> 4;
+    const long img_in = (long)p.ih * p.iw * p.kch * 2, img_out = (long)p.oh * p.ow * p.mch * 2;
+    const vcg_rsrc rw = make_rsrc(p.wf, p.wbytes);
+
+    // LDS byte offset of lane (pixel r + dxo, half hh)'s fragment of channel group s of the chunk: boff[dxo] ^ (s << 5)
+    int boff[SP + 1];
+#pragma unroll
+    for (int d = 0; d <= SP; ++d) {
+        const int pos = r + d;
+        boff[d] = pos * 128 + ((hh ^ ((pos >> 1) & 7)) << 4);
+    }
+    // halo slot of this lane in DMA round k: pixel (row, col), chunk position -- advanced incrementally (32 pixels per round)
+    auto decode = [&](int pair) {
+        const int mg = pair % p.mgroups, t = pair / p.mgroups;
+        const int tx = t % p.tiles_x, t2 = t / p.tiles_x, ty = t2 % p.tiles_y, img = t2 / p.tiles_y;
+        return GlSrc{img, ty * GL_TR + p.dy0, tx * GL_TC + p.dx0, mg, ty, tx};
+    };
+    auto dma = [&](const GlSrc& sc, int c, int buf, int k, bool live) {
+        const int sl = k * 256 + tid, P = sl >> 3, row = P / HC, col = P - row * HC;
+        const int cs = (sl & 7) ^ ((col >> 1) & 7);                                // stored chunk (sl & 7) holds source chunk cs
+        const int iy = sc.y0 + row, ix = sc.x0 + col;
+        const bool ok = live && sl < CH16 && (unsigned)iy < (unsigned)p.ih && (unsigned)ix < (unsigned)p.iw;
+        unsigned off = (unsigned)(((iy * p.iw + ix) * p.kch + c * 64) * 2 + cs * 16);
+        asm volatile("" : "+v"(off));                            // a select, not a branch around the arithmetic
+        off = ok ? off : VCG_OOB;
+        const vcg_rsrc rx = make_rsrc((const unsigned char*)p.x + sc.img * img_in, (unsigned long)img_in);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (void __attribute__((address_space(3)))*)(smem + buf * BUF + (k * 256 + wv * 64) * 16), 16, off, 0, 0, 0);
+    };
+    auto afrag = [&](int wt, int ks, int mtile) {
+        return ld_frag(rw, wt < 0 ? VCG_OOB : (unsigned)(((wt * ksteps + ks) * p.mblocks + mtile) * 1024 + lane * 16));
+    };
+
+    int pair = blockIdx.x;
+    if (pair >= p.pairs) return;
+    GlSrc cur = decode(pair);
+#pragma unroll
+    for (int k = 0; k < NDMA; ++k) dma(cur, 0, 0, k, true);
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    gl_barrier();
+
+    f32x16 acc[GL_TR];
+#pragma unroll
+    for (int n = 0; n < GL_TR; ++n)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[n][e] = 0.f;
+
+    int buf = 0, c = 0;
+    while (true) {
+        // what comes after this (tile, chunk): the next chunk of the tile, or the first chunk of the workgroup's next pair
+        const bool last_chunk = c + 1 == nchunk;
+        const int npair = last_chunk ? pair + gridDim.x : pair;
+        const bool has_next = npair < p.pairs;
+        const GlSrc nxt = last_chunk ? decode(has_next ? npair : pair) : cur;
+        const int nc = last_chunk ? 0 : c + 1;
+        const unsigned char* xb = smem + buf * BUF;
+        const int mtile = cur.mg * 4 + wv;
+
+        bf16x8 fb[2][HR], a[2][SP + 1];
+        auto frag = [&](int g, int b) {
+            const int d = g >> 2, s = g & 3;
+#pragma unroll
+            for (int j = 0; j < HR; ++j) fb[b][j] = *(const bf16x8*)(xb + j * ROWB + (boff[d] ^ (s << 5)));
+        };
+        auto wfrag = [&](int g, int b) {
+            const int d = g >> 2, s = g & 3;
+#pragma unroll
+            for (int dy = 0; dy <= SP; ++dy) a[b][dy] = afrag(p.wt[dy * (SP + 1) + d], c * 4 + s, mtile);
+        };
+        frag(0, 0);
+        wfrag(0, 0);
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const int cb = g & 1;
+            if (g + 1 < G) {
+                wfrag(g + 1, cb ^ 1);                                  // weights one group ahead (older than this group's DMA pieces)
+                frag(g + 1, cb ^ 1);
+            }
+#pragma unroll
+            for (int k = g; k < NDMA; k += G) dma(nxt, nc, buf ^ 1, k, has_next);
+#pragma unroll
+            for (int dy = 0; dy <= SP; ++dy) {
+                if (p.wt[dy * (SP + 1) + (g >> 2)] < 0) continue;     // uniform: a phase of a strided gradient lacks some offsets
+#pragma unroll
+                for (int n = 0; n < GL_TR; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cb][dy], fb[cb][n + dy], acc[n], 0, 0, 0);
+            }
+        }
+        if (last_chunk) {
+            // epilogue: y = act(acc + bias) [* mask] -> bf16; v_permlane32_swap makes 8 consecutive channels per lane (16-byte stores)
+            const float slope = p.act == VCG_ACT_LRELU ? p.alpha : 1.f;
+            const vcg_rsrc ry = make_rsrc((unsigned char*)p.y + cur.img * img_out, (unsigned long)img_out);
+            const vcg_rsrc rm = make_rsrc((const unsigned char*)p.mask_src + cur.img * img_out, (unsigned long)(p.mask_src ? img_out : 0));
+            const int lx = cur.tx * GL_TC + r, ox = lx * p.osx + p.oox;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int co = mtile * 32 + 16 * q + 8 * hh;
+                float bs[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) bs[j] = p.bias ? p.bias[co + j] : 0.f;
+#pragma unroll
+                for (int n = 0; n < GL_TR; ++n) {
+                    const int ly = cur.ty * GL_TR + n, oy = ly * p.osy + p.ooy;
+                    const bool ok = ly < p.loh && lx < p.low && oy < p.oh && ox < p.ow;
+                    unsigned off = (unsigned)(((oy * p.ow + ox) * p.mch + co) * 2);
+                    asm volatile("" : "+v"(off));
+                    off = ok ? off : VCG_OOB;
+                    float v[8];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float lo = acc[n][8 * q + j], hi = acc[n][8 * q + 4 + j];
+                        swap32u(lo, hi);
+                        v[j] = lo;
+                        v[4 + j] = hi;
+                    }
+                    bf16x8 mk;
+                    if (p.mask_src) mk = ld_frag(rm, off);
+                    bf16x8 o;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        float u = v[j] + bs[j];
+                        u = u >= 0.f ? u : u * slope;
+                        if (p.mask_src) u *= ((float)mk[j] > 0.f ? 1.f : p.mask_slope);
+                        o[j] = (__bf16)u;
+                    }
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), ry, (int)off, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int n = 0; n < GL_TR; ++n)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[n][e] = 0.f;
+        }
+        if (last_chunk && !has_next) break;
+        // the next (tile, chunk)'s pieces were issued under this chunk's MFMAs: retire them, then the one barrier of the chunk
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        gl_barrier();
+        buf ^= 1;
+        c = nc;
+        if (last_chunk) { pair = npair; cur = nxt; }
+    }
+}
+
 // out[((wt*ksteps + ks)*mblocks + mb)*64 + lane][j] = W(m = mb*32 + (lane&31), k = ks*16 + 8*(lane>>5) + j, tap wt)
 //   mode 0: W(m, k, t) = w[(t*kdim + k)*mdim + m]     a Keras (kh,kw,in,out) kernel read as conv forward  (m = out, k = in)
 //   mode 1: W(m, k, t) = w[(t*mdim + m)*kdim + k]     the same kernel read for its data gradient          (m = in,  k = out)
@@ -199,9 +384,60 @@ __global__ void f32_to_bf16_kernel(const float* __restrict__ x, __bf16* __restri
     if (i < count) y[i] = (__bf16)x[i];
 }
 
+template <int SP>
+int launch_gconv_lds_sp(const GlParams& q, int grid, hipStream_t st) {
+    constexpr int HR = GL_TR + SP, HC = GL_TC + SP, CH16 = HR * HC * 8, NDMA = (CH16 + 255) / 256, LDS = 2 * NDMA * 4096;
+    static bool attr = false;
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute((const void*)gconv_lds_bf16_kernel<SP>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) return (int)e;
+        attr = true;
+    }
+    hipLaunchKernelGGL(gconv_lds_bf16_kernel<SP>, dim3(grid), dim3(256), LDS, st, q);
+    VCG_LAUNCH_CHECK();
+    return VCG_OK;
+}
+
+// the LDS-tiled kernel where it applies (unit input stride, 64-channel input chunks, 128-channel output groups, taps inside a
+// 5x5 box, images below 4 GiB, enough tiles to fill the chip); VCG_GCONV_LDS=0 forces the streaming kernel (A/B aid)
+bool try_gconv_lds(const GcParams& p, hipStream_t st, int* rc) {
+    static const bool off = getenv("VCG_GCONV_LDS") && atoi(getenv("VCG_GCONV_LDS")) == 0;
+    if (off || p.isy != 1 || p.isx != 1 || p.kch % 64 || p.mblocks % 4 || p.ntaps < 1) return false;
+    if ((long)p.ih * p.iw * p.kch * 2 > 0xFFFFFFE0l || (long)p.oh * p.ow * p.mch * 2 > 0xFFFFFFE0l) return false;
+    int dy0 = 1 << 20, dx0 = 1 << 20, dy1 = -(1 << 20), dx1 = -(1 << 20);
+    for (int i = 0; i < p.ntaps; ++i) {
+        dy0 = p.taps[i].dy < dy0 ? p.taps[i].dy : dy0; dy1 = p.taps[i].dy > dy1 ? p.taps[i].dy : dy1;
+        dx0 = p.taps[i].dx < dx0 ? p.taps[i].dx : dx0; dx1 = p.taps[i].dx > dx1 ? p.taps[i].dx : dx1;
+    }
+    const int sp = (dy1 - dy0 > dx1 - dx0 ? dy1 - dy0 : dx1 - dx0);
+    if (sp > 4 || dy0 < -1000) return false;                    // (the zero-tap sentinel of an empty phase stays on the streaming kernel)
+    GlParams q{};
+    q.x = p.x; q.wf = p.wf; q.y = p.y; q.bias = p.bias; q.mask_src = p.mask_src; q.wbytes = p.wbytes;
+    q.n = p.n; q.ih = p.ih; q.iw = p.iw; q.kch = p.kch; q.oh = p.oh; q.ow = p.ow; q.mch = p.mch; q.loh = p.loh; q.low = p.low;
+    q.osy = p.osy; q.osx = p.osx; q.ooy = p.ooy; q.oox = p.oox; q.mblocks = p.mblocks; q.act = p.act; q.alpha = p.alpha; q.mask_slope = p.mask_slope;
+    q.dy0 = dy0; q.dx0 = dx0;
+    q.tiles_x = ceil_div(p.low, GL_TC); q.tiles_y = ceil_div(p.loh, GL_TR); q.mgroups = p.mblocks / 4;
+    const long pairs = (long)p.n * q.tiles_x * q.tiles_y * q.mgroups;
+    if (pairs < 64 || pairs > 0x7fffffffL) return false;        // too little work for 256 one-workgroup CUs: the streaming kernel's small tiles fill the chip better
+    q.pairs = (int)pairs;
+    const int spe = sp < 1 ? 1 : sp;
+    for (int i = 0; i < 25; ++i) q.wt[i] = -1;
+    for (int i = 0; i < p.ntaps; ++i) q.wt[(p.taps[i].dy - dy0) * (spe + 1) + (p.taps[i].dx - dx0)] = p.taps[i].wt;
+    const int grid = q.pairs < 256 ? q.pairs : 256;
+    switch (spe) {
+        case 1: *rc = launch_gconv_lds_sp<1>(q, grid, st); break;
+        case 2: *rc = launch_gconv_lds_sp<2>(q, grid, st); break;
+        case 3: *rc = launch_gconv_lds_sp<3>(q, grid, st); break;
+        default: *rc = launch_gconv_lds_sp<4>(q, grid, st); break;
+    }
+    return true;
+}
+
 int launch_gconv(GcParams& p, hipStream_t st) {
     const long total = (long)p.n * p.loh * p.low;
     if (total <= 0) return VCG_OK;
+    int lrc = VCG_OK;
+    if (try_gconv_lds(p, st, &lrc)) return lrc;
     const long tiles = (total + 31) / 32;
     // 4 tiles per wave (128 accumulator registers, half the operand loads per MFMA) once there is enough work to fill the chip
     const int mgroups = (p.mblocks + 1) / 2;
