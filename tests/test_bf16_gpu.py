@@ -587,7 +587,10 @@ GCONV_CASES = [
     (256, 512, 4, 1, 1, 2, 70, 50),            # PatchGAN block 4: forward (4x4 box of taps) and data gradient on the LDS kernel, ragged tiles
     (64, 128, 3, 1, "same", 4, 64, 64),        # forward on the LDS kernel (3x3 box)
     (128, 256, 4, 2, 1, 4, 128, 128),          # data gradient of a stride-2 layer: four phases of 2x2 taps
-    (256, 256, 3, 2, "same", 8, 64, 61),       # 3x3 stride 2: phases with one or two taps per dimension (absent offsets in the box), ragged
+    (256, 256, 3, 2, "same", 8, 64, 61),       # 3x3 stride 2: phases / parity planes with one or two taps per dimension (absent offsets), ragged
+    (64, 64, 3, 1, "same", 8, 64, 64),         # 64 output channels: a ragged 128-channel group (two of the four waves compute nothing)
+    (64, 192, 3, 1, "same", 4, 64, 64),        # 192 = one full group + one ragged
+    (64, 128, 4, 2, 1, 4, 128, 96),            # stride-2 forward through the four parity planes (PatchGAN block 2), 64-channel gradient groups
 ]
 
 

@@ -172,8 +172,8 @@ __global__ __launch_bounds__(256, (NT == 4 ? 2 : 4)) void gconv_bf16_kernel(cons
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// LDS-tiled variant for unit input stride (every stride-1 forward convolution and EVERY data gradient: a phase of a strided
-// layer's gradient reads dy at unit stride), 64-channel input chunks, 128 output channels per workgroup
+// LDS-tiled variant: 64-channel input chunks, 128 output channels per workgroup, any stride-1 / stride-2 forward convolution
+// and EVERY data gradient (a phase of a strided layer's gradient reads dy at unit stride)
 // ---------------------------------------------------------------------------------------------------------------
 // The streaming kernel above asks the vector L1 for 32 different 128-byte lines per operand load (one per pixel, 32 bytes of
 // each used) and re-asks for every tap: at the discriminators' 256->512 layer it runs at 220-270 TFLOP/s whatever its
@@ -183,6 +183,9 @@ __global__ __launch_bounds__(256, (NT == 4 ? 2 : 4)) void gconv_bf16_kernel(cons
 // rows of one (dx, channel group) read once for all dy.  Wave w owns 32 of the workgroup's 128 output channels x the tile's
 // 8 rows (128 accumulator registers); its weight fragments stream from L1/L2 as in the kernel above (one coalesced 1-KiB load
 // per 8 MFMAs), requested one k-group ahead.  One LDS-only barrier per chunk.
+// A stride-s forward convolution is the sum over the s x s PARITY PLANES of its input (x_pq[i][j] = x[s*i + p][s*j + q]) of
+// unit-stride convolutions with the taps of that parity (4x4 stride 2: four planes of 2x2 taps): the planes are extra entries of
+// the chunk loop, and the DMA gathers a plane's halo with a pixel stride of s (each pixel still one whole 128-byte line).
 constexpr int GL_TR = 8, GL_TC = 32;
 
 struct GlParams {
@@ -194,9 +197,12 @@ struct GlParams {
     size_t wbytes;
     int n, ih, iw, kch, oh, ow, mch, loh, low, osy, osx, ooy, oox, mblocks, act;
     float alpha, mask_slope;
-    int dy0, dx0;           // smallest tap offsets: halo origin of a tile = (ly0 + dy0, lx0 + dx0)
-    int tiles_x, tiles_y, pairs, mgroups;
-    short wt[25];           // weight tap of offset (dyo, dxo) from the halo origin, row-major (SP+1)^2, or -1
+    int isy, isx;           // input pixel of plane (py, px), plane coordinates (i, j): (isy*i + py, isx*j + px)
+    int tiles_x, tiles_y, pairs, mgroups, nplanes;
+    struct Plane {
+        int py, px, dy0, dx0;     // parity; smallest tap offsets in plane coordinates: halo origin of a tile = (ly0 + dy0, lx0 + dx0)
+        int wt[25];               // weight tap of offset (dyo, dxo) from the halo origin, row-major (SP+1)^2, or -1  (dwords: scalar loads)
+    } pl[4];
 };
 
 struct GlSrc { int img, y0, x0, mg, ty, tx; };       // a (tile, output-channel group) pair: image, halo origin, group, tile coordinates
@@ -215,7 +221,7 @@ __global__ __launch_bounds__(256, 1) void gconv_lds_bf16_kernel(const GlParams p
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, hh = lane >> 5;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nchunk = p.kch >> 6, ksteps = p.kch >> 4;
+    const int nchunk = (p.kch >> 6) * p.nplanes, ksteps = p.kch >> 4;      // chunk = (parity plane, 64 input channels), plane-major
     const long img_in = (long)p.ih * p.iw * p.kch * 2, img_out = (long)p.oh * p.ow * p.mch * 2;
     const vcg_rsrc rw = make_rsrc(p.wf, p.wbytes);
 
@@ -230,21 +236,23 @@ __global__ __launch_bounds__(256, 1) void gconv_lds_bf16_kernel(const GlParams p
     auto decode = [&](int pair) {
         const int mg = pair % p.mgroups, t = pair / p.mgroups;
         const int tx = t % p.tiles_x, t2 = t / p.tiles_x, ty = t2 % p.tiles_y, img = t2 / p.tiles_y;
-        return GlSrc{img, ty * GL_TR + p.dy0, tx * GL_TC + p.dx0, mg, ty, tx};
+        return GlSrc{img, ty * GL_TR, tx * GL_TC, mg, ty, tx};
     };
+    const int cpp = p.kch >> 6;                                  // chunks per plane
     auto dma = [&](const GlSrc& sc, int c, int buf, int k, bool live) {
         const int sl = k * 256 + tid, P = sl >> 3, row = P / HC, col = P - row * HC;
         const int cs = (sl & 7) ^ ((col >> 1) & 7);                                // stored chunk (sl & 7) holds source chunk cs
-        const int iy = sc.y0 + row, ix = sc.x0 + col;
+        const int pli = c / cpp, cc = c - pli * cpp;
+        const int iy = p.isy * (sc.y0 + p.pl[pli].dy0 + row) + p.pl[pli].py, ix = p.isx * (sc.x0 + p.pl[pli].dx0 + col) + p.pl[pli].px;
         const bool ok = live && sl < CH16 && (unsigned)iy < (unsigned)p.ih && (unsigned)ix < (unsigned)p.iw;
-        unsigned off = (unsigned)(((iy * p.iw + ix) * p.kch + c * 64) * 2 + cs * 16);
+        unsigned off = (unsigned)(((iy * p.iw + ix) * p.kch + cc * 64) * 2 + cs * 16);
         asm volatile("" : "+v"(off));                            // a select, not a branch around the arithmetic
         off = ok ? off : VCG_OOB;
         const vcg_rsrc rx = make_rsrc((const unsigned char*)p.x + sc.img * img_in, (unsigned long)img_in);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (void __attribute__((address_space(3)))*)(smem + buf * BUF + (k * 256 + wv * 64) * 16), 16, off, 0, 0, 0);
     };
-    auto afrag = [&](int wt, int ks, int mtile) {
-        return ld_frag(rw, wt < 0 ? VCG_OOB : (unsigned)(((wt * ksteps + ks) * p.mblocks + mtile) * 1024 + lane * 16));
+    auto afrag = [&](int wt, int ks, int mtile) {      // (a wave past the last 32-channel block of a ragged group computes zeros)
+        return ld_frag(rw, wt < 0 || mtile >= p.mblocks ? VCG_OOB : (unsigned)(((wt * ksteps + ks) * p.mblocks + mtile) * 1024 + lane * 16));
     };
 
     int pair = blockIdx.x;
@@ -271,6 +279,7 @@ __global__ __launch_bounds__(256, 1) void gconv_lds_bf16_kernel(const GlParams p
         const int nc = last_chunk ? 0 : c + 1;
         const unsigned char* xb = smem + buf * BUF;
         const int mtile = cur.mg * 4 + wv;
+        const int pli = c / cpp, cc = c - pli * cpp;
 
         bf16x8 fb[2][HR], a[2][SP + 1];
         auto frag = [&](int g, int b) {
@@ -281,7 +290,7 @@ __global__ __launch_bounds__(256, 1) void gconv_lds_bf16_kernel(const GlParams p
         auto wfrag = [&](int g, int b) {
             const int d = g >> 2, s = g & 3;
 #pragma unroll
-            for (int dy = 0; dy <= SP; ++dy) a[b][dy] = afrag(p.wt[dy * (SP + 1) + d], c * 4 + s, mtile);
+            for (int dy = 0; dy <= SP; ++dy) a[b][dy] = afrag(p.pl[pli].wt[dy * (SP + 1) + d], cc * 4 + s, mtile);
         };
         frag(0, 0);
         wfrag(0, 0);
@@ -296,7 +305,7 @@ __global__ __launch_bounds__(256, 1) void gconv_lds_bf16_kernel(const GlParams p
             for (int k = g; k < NDMA; k += G) dma(nxt, nc, buf ^ 1, k, has_next);
 #pragma unroll
             for (int dy = 0; dy <= SP; ++dy) {
-                if (p.wt[dy * (SP + 1) + (g >> 2)] < 0) continue;     // uniform: a phase of a strided gradient lacks some offsets
+                if (p.pl[pli].wt[dy * (SP + 1) + (g >> 2)] < 0) continue;     // uniform: a phase / parity plane lacks some offsets of the box
 #pragma unroll
                 for (int n = 0; n < GL_TR; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cb][dy], fb[cb][n + dy], acc[n], 0, 0, 0);
             }
@@ -312,11 +321,11 @@ __global__ __launch_bounds__(256, 1) void gconv_lds_bf16_kernel(const GlParams p
                 const int co = mtile * 32 + 16 * q + 8 * hh;
                 float bs[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) bs[j] = p.bias ? p.bias[co + j] : 0.f;
+                for (int j = 0; j < 8; ++j) bs[j] = p.bias && mtile < p.mblocks ? p.bias[co + j] : 0.f;
 #pragma unroll
                 for (int n = 0; n < GL_TR; ++n) {
                     const int ly = cur.ty * GL_TR + n, oy = ly * p.osy + p.ooy;
-                    const bool ok = ly < p.loh && lx < p.low && oy < p.oh && ox < p.ow;
+                    const bool ok = ly < p.loh && lx < p.low && oy < p.oh && ox < p.ow && mtile < p.mblocks;
                     unsigned off = (unsigned)(((oy * p.ow + ox) * p.mch + co) * 2);
                     asm volatile("" : "+v"(off));
                     off = ok ? off : VCG_OOB;
@@ -398,31 +407,52 @@ int launch_gconv_lds_sp(const GlParams& q, int grid, hipStream_t st) {
     return VCG_OK;
 }
 
-// the LDS-tiled kernel where it applies (unit input stride, 64-channel input chunks, 128-channel output groups, taps inside a
-// 5x5 box, images below 4 GiB, enough tiles to fill the chip); VCG_GCONV_LDS=0 forces the streaming kernel (A/B aid)
+// the LDS-tiled kernel where it applies (input stride 1 or 2, 64-channel input chunks, >= 64 output channels, the taps of a parity plane
+// inside a 5x5 box, images below 4 GiB, enough tiles to fill the chip); VCG_GCONV_LDS=0 forces the streaming kernel (A/B aid)
 bool try_gconv_lds(const GcParams& p, hipStream_t st, int* rc) {
     static const bool off = getenv("VCG_GCONV_LDS") && atoi(getenv("VCG_GCONV_LDS")) == 0;
-    if (off || p.isy != 1 || p.isx != 1 || p.kch % 64 || p.mblocks % 4 || p.ntaps < 1) return false;
+    if (off || p.isy != p.isx || p.isy < 1 || p.isy > 2 || p.kch % 64 || p.mblocks < 2 || p.ntaps < 1) return false;
     if ((long)p.ih * p.iw * p.kch * 2 > 0xFFFFFFE0l || (long)p.oh * p.ow * p.mch * 2 > 0xFFFFFFE0l) return false;
-    int dy0 = 1 << 20, dx0 = 1 << 20, dy1 = -(1 << 20), dx1 = -(1 << 20);
-    for (int i = 0; i < p.ntaps; ++i) {
-        dy0 = p.taps[i].dy < dy0 ? p.taps[i].dy : dy0; dy1 = p.taps[i].dy > dy1 ? p.taps[i].dy : dy1;
-        dx0 = p.taps[i].dx < dx0 ? p.taps[i].dx : dx0; dx1 = p.taps[i].dx > dx1 ? p.taps[i].dx : dx1;
-    }
-    const int sp = (dy1 - dy0 > dx1 - dx0 ? dy1 - dy0 : dx1 - dx0);
-    if (sp > 4 || dy0 < -1000) return false;                    // (the zero-tap sentinel of an empty phase stays on the streaming kernel)
     GlParams q{};
+    // taps by the parity plane of the input they read: dy = isy * a + py
+    const int S = p.isy;
+    int sp = 0;
+    for (int py = 0; py < S; ++py)
+        for (int px = 0; px < S; ++px) {
+            int a0 = 1 << 20, b0 = 1 << 20, a1 = -(1 << 20), b1 = -(1 << 20), cnt = 0;
+            for (int i = 0; i < p.ntaps; ++i) {
+                const int dy = p.taps[i].dy, dx = p.taps[i].dx;
+                if (dy < -1000) return false;                                  // (the zero-tap sentinel of an empty phase stays on the streaming kernel)
+                if (((dy % S) + S) % S != py || ((dx % S) + S) % S != px) continue;
+                const int a = (dy - py) / S, b = (dx - px) / S;               // exact: dy - py is a multiple of S
+                a0 = a < a0 ? a : a0; a1 = a > a1 ? a : a1; b0 = b < b0 ? b : b0; b1 = b > b1 ? b : b1;
+                ++cnt;
+            }
+            if (!cnt) continue;
+            GlParams::Plane& pl = q.pl[q.nplanes++];
+            pl.py = py; pl.px = px; pl.dy0 = a0; pl.dx0 = b0;
+            const int span = a1 - a0 > b1 - b0 ? a1 - a0 : b1 - b0;
+            sp = span > sp ? span : sp;
+        }
+    if (sp > 4 || q.nplanes < 1) return false;
+    const int spe = sp < 1 ? 1 : sp;
+    for (int k = 0; k < q.nplanes; ++k) {
+        GlParams::Plane& pl = q.pl[k];
+        for (int i = 0; i < 25; ++i) pl.wt[i] = -1;
+        for (int i = 0; i < p.ntaps; ++i) {
+            const int dy = p.taps[i].dy, dx = p.taps[i].dx;
+            if (((dy % S) + S) % S != pl.py || ((dx % S) + S) % S != pl.px) continue;
+            pl.wt[((dy - pl.py) / S - pl.dy0) * (spe + 1) + ((dx - pl.px) / S - pl.dx0)] = p.taps[i].wt;
+        }
+    }
     q.x = p.x; q.wf = p.wf; q.y = p.y; q.bias = p.bias; q.mask_src = p.mask_src; q.wbytes = p.wbytes;
     q.n = p.n; q.ih = p.ih; q.iw = p.iw; q.kch = p.kch; q.oh = p.oh; q.ow = p.ow; q.mch = p.mch; q.loh = p.loh; q.low = p.low;
     q.osy = p.osy; q.osx = p.osx; q.ooy = p.ooy; q.oox = p.oox; q.mblocks = p.mblocks; q.act = p.act; q.alpha = p.alpha; q.mask_slope = p.mask_slope;
-    q.dy0 = dy0; q.dx0 = dx0;
-    q.tiles_x = ceil_div(p.low, GL_TC); q.tiles_y = ceil_div(p.loh, GL_TR); q.mgroups = p.mblocks / 4;
+    q.isy = p.isy; q.isx = p.isx;
+    q.tiles_x = ceil_div(p.low, GL_TC); q.tiles_y = ceil_div(p.loh, GL_TR); q.mgroups = (p.mblocks + 3) / 4;
     const long pairs = (long)p.n * q.tiles_x * q.tiles_y * q.mgroups;
     if (pairs < 64 || pairs > 0x7fffffffL) return false;        // too little work for 256 one-workgroup CUs: the streaming kernel's small tiles fill the chip better
     q.pairs = (int)pairs;
-    const int spe = sp < 1 ? 1 : sp;
-    for (int i = 0; i < 25; ++i) q.wt[i] = -1;
-    for (int i = 0; i < p.ntaps; ++i) q.wt[(p.taps[i].dy - dy0) * (spe + 1) + (p.taps[i].dx - dx0)] = p.taps[i].wt;
     const int grid = q.pairs < 256 ? q.pairs : 256;
     switch (spe) {
         case 1: *rc = launch_gconv_lds_sp<1>(q, grid, st); break;
