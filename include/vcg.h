@@ -315,6 +315,12 @@ size_t vcg_conv2d_bf16_wgrad_workspace_bytes(const vcg_conv_desc* d);
 int vcg_conv2d_bf16_wgrad(const vcg_conv_desc* d, const void* x, const void* dy, float* dw_hwio, float* dbias, void* ws, size_t ws_bytes,
                           hipStream_t stream);
 
+/* weight gradient of final/conv -- Conv2D(3, 9, 'same') on 256 channels (upscaling/upscaler/model.py:290) -- in the bf16 configs:
+ * x bf16 NHWC [n][h][w][256], dz fp32 NCHW [n][3][h][w] (the gradient behind the tanh; rounded to bf16 as an MFMA operand), dw fp32 in
+ * Keras' (9,9,256,3) layout, overwritten.  w must be even.  (The bias gradient is the channel sum of dz: vcg_act_bwd / vcg_channel_sum.) */
+size_t vcg_conv9x9_to3_bf16_wgrad_workspace_bytes(const vcg_conv_desc* d);
+int vcg_conv9x9_to3_bf16_wgrad(const vcg_conv_desc* d, const void* x, const float* dz, float* dw_hwio, void* ws, size_t ws_bytes, hipStream_t stream);
+
 /* ---- generic bf16 NHWC Conv2D (any 3x3 / 4x4 / 5x5, stride 1-3, channels multiples of 32 / 16): the discriminators' layers in
  * the bf16 configs (upscaling/upscaler/model.py:839-871, 904-936; PatchGAN) and the generator's Conv2DTranspose gradients.
  * Weights as MFMA operand fragments: vcg_pack_conv_frag_bf16(w, taps, mdim, kdim, mode, out), out = taps*mdim*kdim bf16:

@@ -536,6 +536,34 @@ def test_final_conv9x9_bf16_dgrad(rt, n, h, w, mask):
     assert e < TOL_BF16
 
 
+@pytest.mark.parametrize("n,h,w", [(1, 16, 32), (2, 37, 70), (1, 5, 10), (3, 64, 96)])
+def test_final_conv9x9_bf16_wgrad(rt, n, h, w):
+    """weight gradient of final/conv on the bf16 path: x bf16 NHWC by transposed LDS reads, dz as a bf16 operand (8 taps x (3 + 1)
+    channels per MFMA column tile), against the fp64 oracle on the same rounded operands; deterministic"""
+    from oracle import keras_ops as K
+    from upscaler import _lib as L
+    g = torch.Generator().manual_seed(n * 100 + h + w)
+    x = torch.randn(n, 256, h, w, generator=g)
+    dz = torch.randn(n, 3, h, w, generator=g)
+    wk = torch.zeros(9, 9, 256, 3, dtype=torch.float64, requires_grad=True)
+    (K.conv2d(_bf16_round(x), wk, None, 1, "same") * _bf16_round(dz)).sum().backward()
+    xd = _to_nhwc_bf16(rt, x.to(rt.device))
+    dzd = dz.to(rt.device)
+    d = L.ConvDesc(n, 256, h, w, 3, h, w, 9, 9, 1, 4, 4)
+    ws, wsn = rt.workspace(rt.lib.vcg_conv9x9_to3_bf16_wgrad_workspace_bytes(ctypes.byref(d)))
+    outs = []
+    for _ in range(2):
+        dw = torch.full((9, 9, 256, 3), float("nan"), device=rt.device)
+        L.check(rt.lib.vcg_conv9x9_to3_bf16_wgrad(ctypes.byref(d), xd.data_ptr(), dzd.data_ptr(), dw.data_ptr(), ws, wsn, rt.stream), "vcg_conv9x9_to3_bf16_wgrad")
+        outs.append(dw.clone())
+    e = rel_err(outs[0], wk.grad)
+    report("bf16 final conv wgrad 256->3 n=%d %dx%d err=%.2e" % (n, h, w, e))
+    assert e < 1e-5
+    assert torch.equal(outs[0], outs[1])
+    dodd = L.ConvDesc(n, 256, h, w + 1, 3, h, w + 1, 9, 9, 1, 4, 4)
+    assert rt.lib.vcg_conv9x9_to3_bf16_wgrad(ctypes.byref(dodd), xd.data_ptr(), dzd.data_ptr(), dw.data_ptr(), ws, wsn, rt.stream) == -3      # VCG_E_UNSUPPORTED: odd width
+
+
 @pytest.mark.parametrize("mode", ["bf16", "bf16+tail"])
 def test_bf16_generator_modes_graph_replay_matches_eager(rt, mode):
     """the mixed-precision generator modes inside the captured train step: bf16 weight copies are re-packed inside the graph after

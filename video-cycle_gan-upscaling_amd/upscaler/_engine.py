@@ -816,8 +816,8 @@ class ConvT3x3Bf16(ConvT2D):
 class FinalConv9x9Bf16(Conv2D):
     """final/conv (model.py:290-291): Conv2D(3, 9) + tanh on a bf16 NHWC input with 256 channels, fp32 NCHW output.  Forward on
     vcg_conv9x9_to3_bf16_fwd; data gradient on vcg_conv9x9_to3_bf16_dgrad, which also applies the derivative of the LeakyReLU that
-    produced the input (so the result is the gradient in front of that activation); the weight gradient still runs the fp32 kernel
-    on an fp32 NCHW copy of the input (exact conversion)."""
+    produced the input (so the result is the gradient in front of that activation); weight gradient on vcg_conv9x9_to3_bf16_wgrad
+    (even widths; odd ones take the fp32 kernel on an fp32 NCHW copy of the input)."""
 
     def __init__(self, name, cin, cout, k, act=L.ACT_TANH):
         if cin != 256 or cout != 3 or k != 9:
@@ -866,7 +866,18 @@ class FinalConv9x9Bf16(Conv2D):
             L.check(rt.lib.vcg_act_bwd(y.data_ptr(), dy.data_ptr(), n, 3, d.oh * d.ow, self.act, 0.0, None, dz.data_ptr(), None, db, ws, wsn,
                                        rt.stream), "vcg_act_bwd[%s]" % self.name)
             dy, db_done = dz, True
-        if param_grads:
+        if param_grads and d.w % 2 == 0:
+            # bf16 weight gradient straight from the bf16 NHWC input (transposed LDS reads); dz enters as a bf16 MFMA operand
+            ws, wsn = rt.workspace(max(rt.lib.vcg_conv9x9_to3_bf16_wgrad_workspace_bytes(ctypes.byref(d)),
+                                       rt.lib.vcg_channel_sum_workspace_bytes(n, 3, d.oh * d.ow)))
+            with Timed(rt, tag and tag + "_wgrad"):
+                L.check(rt.lib.vcg_conv9x9_to3_bf16_wgrad(ctypes.byref(d), x.data_ptr(), dy.data_ptr(), self.ps.grad(self.name + "/kernel", which).data_ptr(),
+                                                          ws, wsn, rt.stream), "vcg_conv9x9_to3_bf16_wgrad[%s]" % self.name)
+            if not db_done:
+                L.check(rt.lib.vcg_channel_sum(dy.data_ptr(), n, 3, d.oh * d.ow, self.ps.grad(self.name + "/bias", which).data_ptr(), ws, wsn,
+                                               rt.stream), "vcg_channel_sum[%s]" % self.name)
+        elif param_grads:
+            # odd widths: the fp32 kernel on an fp32 NCHW copy of the input (exact conversion)
             x32 = from_bf16_nhwc(rt, x)
             ws, wsn = rt.workspace(rt.lib.vcg_conv2d_wgrad_workspace_bytes(ctypes.byref(d)))
             with Timed(rt, tag and tag + "_wgrad"):

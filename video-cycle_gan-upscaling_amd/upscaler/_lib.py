@@ -109,6 +109,8 @@ SIGNATURES = {
                                       c_size_t, _P]),
     "vcg_conv2d_bf16_wgrad_workspace_bytes": (c_size_t, [_D]),
     "vcg_conv2d_bf16_wgrad": (c_int, [_D, _P, _P, _P, _P, _P, c_size_t, _P]),
+    "vcg_conv9x9_to3_bf16_wgrad_workspace_bytes": (c_size_t, [_D]),
+    "vcg_conv9x9_to3_bf16_wgrad": (c_int, [_D, _P, _P, _P, _P, c_size_t, _P]),
     "vcg_pack_first9x9_bf16": (c_int, [_P, _P, _P]),
     "vcg_pack_conv9x9_3ch_bf16": (c_int, [_P, c_int, c_int, _P, _P]),
     "vcg_conv9x9_to3_bf16_dgrad": (c_int, [_D, _P, _P, _P, c_float, _P, _P]),
