@@ -332,6 +332,11 @@ int vcg_pack_conv_frag_bf16(const float* w, int taps, int mdim, int kdim, int mo
 /* y = act(conv(x) + bias), x / y bf16 NHWC, bias fp32 [cout] or NULL, act VCG_ACT_NONE / VCG_ACT_LRELU */
 int vcg_conv2d_nhwc_bf16_fwd(const vcg_conv_desc* d, const void* x, const void* wfrag, const float* bias, int act, float act_alpha,
                              void* y, hipStream_t stream);
+/* Conv2DTranspose(k, strides 2, 'same') + bias + LeakyReLU (model.py:72-73) on bf16 NHWC as the data gradient of the stride-2 convolution its
+ * kernel is: d describes the transposed layer (cin, h, w -> cout, oh, ow; pads = the 'same' crop), wfrag =
+ * vcg_pack_conv_frag_bf16(kernel (kh,kw,out,in), k*k, mdim = cout, kdim = cin, mode 1) */
+int vcg_conv_transpose2d_nhwc_bf16_fwd(const vcg_conv_desc* d, const void* x, const void* wfrag, const float* bias, int act, float act_alpha,
+                                       void* y, hipStream_t stream);
 /* dx = data gradient of the layer d describes (d is the FORWARD layer), dy / dx bf16 NHWC, wfrag_t packed with mode 1.
  * mask_src (optional, bf16 NHWC of dx's shape): dx *= (mask_src > 0 ? 1 : mask_slope), the derivative of a LeakyReLU whose
  * OUTPUT mask_src is and which feeds the layer. */

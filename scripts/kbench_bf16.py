@@ -81,6 +81,20 @@ def bench_convt(B):
     print("%-28s B=%d  %.3f ms  %7.1f TFLOP/s (%.1f%% of %.0f)  %6.0f GB/s algorithmic (%.1f%% of %.0f)"
           % ("convT 3x3 s2 64->256 +LReLU", B, ms, flop / ms / 1e9, 100 * flop / ms / 1e9 / PEAK_TF, PEAK_TF, nbytes / ms / 1e6,
              100 * nbytes / ms / 1e6 / PEAK_GBS, PEAK_GBS), flush=True)
+    # the same layer as four phase launches of the LDS-tiled generic kernel
+    wsrc = torch.randn(3, 3, 256, 64, device=dev) * 0.05
+    wfr = torch.empty(9 * 256 * 64, dtype=torch.bfloat16, device=dev)
+    L.check(rt.lib.vcg_pack_conv_frag_bf16(wsrc.data_ptr(), 9, 256, 64, 1, wfr.data_ptr(), rt.stream), "pack")
+    bias = torch.zeros(256, device=dev)
+
+    def run2():
+        L.check(rt.lib.vcg_conv_transpose2d_nhwc_bf16_fwd(ctypes.byref(d), x.data_ptr(), wfr.data_ptr(), bias.data_ptr(), L.ACT_LRELU, 0.2, y.data_ptr(),
+                                                          rt.stream), "convT generic")
+    if y.numel() * 2 <= 0xFFFFFFE0:                     # the generic kernels address a whole tensor through one buffer descriptor (< 4 GiB)
+        ms = timeit(run2)
+        print("%-28s B=%d  %.3f ms  %7.1f TFLOP/s (%.1f%% of %.0f)  %6.0f GB/s algorithmic (%.1f%% of %.0f)"
+              % ("  .. as 4 generic phases", B, ms, flop / ms / 1e9, 100 * flop / ms / 1e9 / PEAK_TF, PEAK_TF, nbytes / ms / 1e6,
+                 100 * nbytes / ms / 1e6 / PEAK_GBS, PEAK_GBS), flush=True)
 
 
 def bench_final(B):

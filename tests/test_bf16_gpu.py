@@ -128,6 +128,7 @@ CT_CASES = [
     (1, 13, 45, 128, True),         # ragged tile edges
     (2, 40, 72, 256, True),         # upsampling_block(64 -> 256)
     (1, 5, 7, 256, True),
+    (4, 64, 96, 256, True),         # enough tiles for the LDS-tiled generic kernel (each phase: 4 x 8 x 3 tiles x 2 groups)
 ]
 
 
@@ -158,6 +159,17 @@ def test_conv_transpose3x3_s2_bf16(rt, n, h, w, cout, lrelu):
     report("bf16 convT3x3 s2 64->%d n=%d %dx%d lrelu=%s  err=%.2e  elementwise(ulp-scaled)=%.2f" % (cout, n, h, w, lrelu, e, ew))
     assert e < TOL_BF16
     assert ew < 1.0
+    # the same layer as the data gradient of the stride-2 convolution its kernel is (four phase launches of the generic kernels)
+    wfr = torch.empty(9 * cout * 64, dtype=torch.bfloat16, device=rt.device)
+    L.check(rt.lib.vcg_pack_conv_frag_bf16(wd.data_ptr(), 9, cout, 64, 1, wfr.data_ptr(), rt.stream), "pack frag")
+    y2 = torch.full_like(y, float("nan"))
+    L.check(rt.lib.vcg_conv_transpose2d_nhwc_bf16_fwd(ctypes.byref(d), xd.data_ptr(), wfr.data_ptr(), bd.data_ptr(), L.ACT_LRELU if lrelu else L.ACT_NONE, 0.2,
+                                                      y2.data_ptr(), rt.stream), "vcg_conv_transpose2d_nhwc_bf16_fwd")
+    got2 = _to_nchw_f32(rt, y2).cpu().double()
+    e2 = rel_err(got2, ref)
+    ew2 = float(((got2 - ref).abs() / (ref.abs() * 2.0 ** -8 + 1e-3 * ref.abs().max())).max())
+    report("  .. generic (phases): err=%.2e  elementwise(ulp-scaled)=%.2f" % (e2, ew2))
+    assert e2 < TOL_BF16 and ew2 < 1.0
 
 
 F9_CASES = [

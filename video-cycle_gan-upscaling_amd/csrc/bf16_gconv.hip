@@ -592,4 +592,52 @@ int vcg_conv2d_nhwc_bf16_dgrad(const vcg_conv_desc* d, const void* dy, const voi
     return VCG_OK;
 }
 
+// y[n][2h][2w][cout] = act(conv_transpose(x) + bias) for Conv2DTranspose(k, strides 2, 'same') (model.py:72): the data gradient of the
+// stride-2 convolution whose Keras kernel (kh, kw, in' = cout, out' = cin) the transposed kernel (kh, kw, out, in) already is -- one
+// launch per output phase, through the LDS-tiled kernel where it applies.  d: the transposed layer (cin, h, w -> cout, oh, ow; pads =
+// the 'same' crop); wfrag: vcg_pack_conv_frag_bf16(kernel, k*k, mdim = cout, kdim = cin, mode 1).
+int vcg_conv_transpose2d_nhwc_bf16_fwd(const vcg_conv_desc* d, const void* x, const void* wfrag, const float* bias, int act, float act_alpha,
+                                       void* y, hipStream_t stream) {
+    if (d == nullptr) return VCG_E_NULL;
+    VCG_CHECK_PTR(x); VCG_CHECK_PTR(wfrag); VCG_CHECK_PTR(y);
+    if (d->n <= 0 || d->cin <= 0 || d->cout <= 0 || d->h <= 0 || d->w <= 0 || d->oh <= 0 || d->ow <= 0) return VCG_E_SHAPE;
+    if (d->stride != 2 || d->kh != d->kw || d->kh * d->kw > GC_MAXTAPS || d->cin % 16 || d->cout % 32) return VCG_E_UNSUPPORTED;
+    if (d->oh > 2 * d->h || d->ow > 2 * d->w || d->pad_top < 0 || d->pad_left < 0 || d->pad_top >= d->kh || d->pad_left >= d->kw) return VCG_E_SHAPE;
+    if (act != VCG_ACT_NONE && act != VCG_ACT_LRELU) return VCG_E_UNSUPPORTED;
+    if ((size_t)d->n * d->h * d->w * d->cin * 2 > 0xFFFFFFE0u || (size_t)d->n * d->oh * d->ow * d->cout * 2 > 0xFFFFFFE0u) return VCG_E_SHAPE;
+    GcParams p{};
+    p.x = x; p.wf = wfrag; p.y = y; p.bias = bias;
+    p.wbytes = vcg_conv_frag_bf16_bytes(d->kh * d->kw, d->cout, d->cin);
+    p.n = d->n; p.ih = d->h; p.iw = d->w; p.kch = d->cin;
+    p.oh = d->oh; p.ow = d->ow; p.mch = d->cout;
+    p.isy = p.isx = 1;
+    p.mblocks = d->cout / 32;
+    p.act = act; p.alpha = act_alpha;
+    const int S = 2;
+    p.osy = p.osx = S;
+    int rc = VCG_OK;
+    for (int py = 0; py < S; ++py)
+        for (int px = 0; px < S; ++px) {
+            p.ooy = py; p.oox = px;
+            p.loh = (d->oh - py + S - 1) / S;
+            p.low = (d->ow - px + S - 1) / S;
+            p.ntaps = 0;
+            for (int ky = 0; ky < d->kh; ++ky) {
+                if ((py + d->pad_top - ky) % S) continue;
+                for (int kx = 0; kx < d->kw; ++kx) {
+                    if ((px + d->pad_left - kx) % S) continue;
+                    p.taps[p.ntaps++] = GcTap{(short)((py + d->pad_top - ky) / S), (short)((px + d->pad_left - kx) / S), (short)(ky * d->kw + kx), 0};
+                }
+            }
+            if (p.loh <= 0 || p.low <= 0) continue;
+            if (p.ntaps == 0) {
+                p.taps[0] = GcTap{(short)-30000, (short)-30000, 0, 0};
+                p.ntaps = 1;
+            }
+            rc = launch_gconv(p, stream);
+            if (rc) return rc;
+        }
+    return VCG_OK;
+}
+
 }  // extern "C"

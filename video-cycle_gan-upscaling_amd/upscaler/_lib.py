@@ -121,6 +121,7 @@ SIGNATURES = {
     "vcg_conv_frag_bf16_bytes": (c_size_t, [c_int, c_int, c_int]),
     "vcg_pack_conv_frag_bf16": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P]),
     "vcg_conv2d_nhwc_bf16_fwd": (c_int, [_D, _P, _P, _P, c_int, c_float, _P, _P]),
+    "vcg_conv_transpose2d_nhwc_bf16_fwd": (c_int, [_D, _P, _P, _P, c_int, c_float, _P, _P]),
     "vcg_conv2d_nhwc_bf16_dgrad": (c_int, [_D, _P, _P, _P, c_float, _P, _P]),
     "vcg_conv2d_nhwc_bf16_wgrad_workspace_bytes": (c_size_t, [_D]),
     "vcg_conv2d_nhwc_bf16_wgrad": (c_int, [_D, _P, _P, _P, _P, _P, c_size_t, _P]),
