@@ -14,25 +14,30 @@ constexpr int SPB = 512;         // pixels per block of the partial passes (4 bl
 
 // partial sums of (x - K) and (x - K)^2 per channel over a slab of pixels; K = the group's first pixel (a shift
 // that keeps E[d^2] - E[d]^2 from cancelling when |mean| >> std).  group = image (instance) or the whole batch.
+// A block walks the slabs b, b + bpg, ... of its group (bpg blocks per group, at most NBLK in all): one LDS reduction and one partial
+// record per BLOCK, so the final pass sums <= NBLK records instead of one per 512 pixels (1024 at the C2 trunk shape: 15 us in a
+// single workgroup).
 __global__ __launch_bounds__(256) void stats_partial_bf16_kernel(const bf16x8* __restrict__ x, int c8, long group_pixels,
-                                                                  int slabs_per_group, float* __restrict__ part) {
+                                                                  int slabs_per_group, int bpg, float* __restrict__ part) {
     extern __shared__ float red[];                                   // [256 / c8 lanes... ] see below
-    const int grp = blockIdx.x / slabs_per_group, slab = blockIdx.x - grp * slabs_per_group;
+    const int grp = blockIdx.x / bpg, blk = blockIdx.x - grp * bpg;
     const int ch = threadIdx.x % c8, pl = threadIdx.x / c8, npl = 256 / c8;
     const bf16x8* xg = x + (long)grp * group_pixels * c8;
     const bf16x8 k8 = xg[ch];
     float s[8], q[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) s[j] = q[j] = 0.f;
-    const long p0 = (long)slab * SPB, p1 = p0 + SPB < group_pixels ? p0 + SPB : group_pixels;
     if (pl < npl)
-        for (long p = p0 + pl; p < p1; p += npl) {
-            const bf16x8 v = xg[p * c8 + ch];
+        for (int slab = blk; slab < slabs_per_group; slab += bpg) {
+            const long p0 = (long)slab * SPB, p1 = p0 + SPB < group_pixels ? p0 + SPB : group_pixels;
+            for (long p = p0 + pl; p < p1; p += npl) {
+                const bf16x8 v = xg[p * c8 + ch];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float d = (float)v[j] - (float)k8[j];
-                s[j] += d;
-                q[j] += d * d;
+                for (int j = 0; j < 8; ++j) {
+                    const float d = (float)v[j] - (float)k8[j];
+                    s[j] += d;
+                    q[j] += d * d;
+                }
             }
         }
     // fixed-order reduction over the pixel lanes
@@ -61,12 +66,22 @@ __global__ __launch_bounds__(1024) void stats_final_bf16_kernel(const __bf16* __
     __shared__ double rs[16][64], rq[16][64];
     const int cblocks = (c + 63) / 64, grp = blockIdx.x / cblocks, ch = (blockIdx.x - grp * cblocks) * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
     double s = 0.0, q = 0.0;
-    if (ch < c)
-        for (int b = g; b < slabs_per_group; b += 16) {
+    if (ch < c) {
+        // four records in flight per thread (one at a time left this single-workgroup pass latency-bound: 15 us for 1024 records)
+        int b = g;
+        for (; b + 48 < slabs_per_group; b += 64) {
+            float2 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = *(const float2*)(part + (((long)grp * slabs_per_group + b + 16 * u) * c + ch) * 2);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { s += v[u].x; q += v[u].y; }
+        }
+        for (; b < slabs_per_group; b += 16) {
             const float* pp = part + (((long)grp * slabs_per_group + b) * c + ch) * 2;
             s += pp[0];
             q += pp[1];
         }
+    }
     rs[g][threadIdx.x & 63] = s;
     rq[g][threadIdx.x & 63] = q;
     __syncthreads();
@@ -131,10 +146,10 @@ __global__ __launch_bounds__(256) void norm_bwd_partial_bf16_kernel(const bf16x8
                                                                      long group_pixels, int slabs_per_group, int per_sample,
                                                                      const float* __restrict__ mean, const float* __restrict__ invstd,
                                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                                     int act, float alpha, const float* __restrict__ prelu,
+                                                                     int act, float alpha, const float* __restrict__ prelu, int bpg,
                                                                      float* __restrict__ part) {
     extern __shared__ float red[];                                   // [3][256*8]
-    const int grp = blockIdx.x / slabs_per_group, slab = blockIdx.x - grp * slabs_per_group;
+    const int grp = blockIdx.x / bpg, blk = blockIdx.x - grp * bpg;
     const int ch = threadIdx.x % c8, pl = threadIdx.x / c8, npl = 256 / c8;
     const long gbase = (long)grp * group_pixels * c8;
     const int sidx = (per_sample ? grp * c8 * 8 : 0) + ch * 8;
@@ -148,17 +163,19 @@ __global__ __launch_bounds__(256) void norm_bwd_partial_bf16_kernel(const bf16x8
         sl[j] = act == VCG_ACT_PRELU ? prelu[ch * 8 + j] : alpha;
         s1[j] = s2[j] = s3[j] = 0.f;
     }
-    const long p0 = (long)slab * SPB, p1 = p0 + SPB < group_pixels ? p0 + SPB : group_pixels;
     if (pl < npl)
-        for (long p = p0 + pl; p < p1; p += npl) {
-            const bf16x8 xv = x[gbase + p * c8 + ch], dv = dy[gbase + p * c8 + ch];
+        for (int slab = blk; slab < slabs_per_group; slab += bpg) {
+            const long p0 = (long)slab * SPB, p1 = p0 + SPB < group_pixels ? p0 + SPB : group_pixels;
+            for (long p = p0 + pl; p < p1; p += npl) {
+                const bf16x8 xv = x[gbase + p * c8 + ch], dv = dy[gbase + p * c8 + ch];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float xh = ((float)xv[j] - mu[j]) * is[j], u = xh * ga[j] + be[j], d = (float)dv[j];
-                const float dz = d * act_grad_bf16(u, act, sl[j]);
-                s1[j] += dz;
-                s2[j] += dz * xh;
-                s3[j] += d * fminf(u, 0.f);
+                for (int j = 0; j < 8; ++j) {
+                    const float xh = ((float)xv[j] - mu[j]) * is[j], u = xh * ga[j] + be[j], d = (float)dv[j];
+                    const float dz = d * act_grad_bf16(u, act, sl[j]);
+                    s1[j] += dz;
+                    s2[j] += dz * xh;
+                    s3[j] += d * fminf(u, 0.f);
+                }
             }
         }
 #pragma unroll
@@ -189,13 +206,25 @@ __global__ __launch_bounds__(1024) void norm_bwd_sums_bf16_kernel(const float* _
     __shared__ double r1[16][64], r2[16][64], r3[16][64];
     const int cblocks = (c + 63) / 64, grp = blockIdx.x / cblocks, ch = (blockIdx.x - grp * cblocks) * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
     double s1 = 0.0, s2 = 0.0, s3 = 0.0;
-    if (ch < c)
-        for (int b = g; b < slabs_per_group; b += 16) {
+    if (ch < c) {
+        int b = g;
+        for (; b + 48 < slabs_per_group; b += 64) {           // four records in flight per thread, summed in record order
+            float v[4][3];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float* pp = part + (((long)grp * slabs_per_group + b + 16 * u) * c + ch) * 3;
+                v[u][0] = pp[0]; v[u][1] = pp[1]; v[u][2] = pp[2];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { s1 += v[u][0]; s2 += v[u][1]; s3 += v[u][2]; }
+        }
+        for (; b < slabs_per_group; b += 16) {
             const float* pp = part + (((long)grp * slabs_per_group + b) * c + ch) * 3;
             s1 += pp[0];
             s2 += pp[1];
             s3 += pp[2];
         }
+    }
     r1[g][threadIdx.x & 63] = s1;
     r2[g][threadIdx.x & 63] = s2;
     r3[g][threadIdx.x & 63] = s3;
@@ -266,6 +295,14 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_bf16_kernel(const bf16x8* 
     }
 }
 
+// blocks per group of the partial passes: one per slab up to NBLK blocks in all (2 per CU, each walking several slabs)
+constexpr int NBLK = 512;
+inline int blocks_per_group(int slabs, int groups) {
+    int b = NBLK / groups;
+    b = b < 1 ? 1 : b;
+    return slabs < b ? slabs : b;
+}
+
 }  // namespace
 
 extern "C" {
@@ -284,10 +321,10 @@ int vcg_norm_stats_bf16(const void* x, int n, int c, int hw, int mode, float* me
     if (ws_bytes < vcg_norm_stats_bf16_workspace_bytes(n, c, hw, mode)) return VCG_E_WORKSPACE;
     const long gp = mode == VCG_NORM_INSTANCE ? hw : (long)n * hw;
     const int groups = mode == VCG_NORM_INSTANCE ? n : 1;
-    const int slabs = (int)((gp + SPB - 1) / SPB);
-    stats_partial_bf16_kernel<<<groups * slabs, 256, 2 * 256 * 8 * sizeof(float), stream>>>((const bf16x8*)x, c / 8, gp, slabs, (float*)ws);
+    const int slabs = (int)((gp + SPB - 1) / SPB), bpg = blocks_per_group(slabs, groups);
+    stats_partial_bf16_kernel<<<groups * bpg, 256, 2 * 256 * 8 * sizeof(float), stream>>>((const bf16x8*)x, c / 8, gp, slabs, bpg, (float*)ws);
     VCG_LAUNCH_CHECK();
-    stats_final_bf16_kernel<<<groups * ceil_div(c, 64), 1024, 0, stream>>>((const __bf16*)x, (const float*)ws, c, gp, slabs, groups, mean, var);
+    stats_final_bf16_kernel<<<groups * ceil_div(c, 64), 1024, 0, stream>>>((const __bf16*)x, (const float*)ws, c, gp, bpg, groups, mean, var);
     VCG_LAUNCH_CHECK();
     return VCG_OK;
 }
@@ -323,14 +360,14 @@ int vcg_norm_act_bwd_bf16(const void* x, const void* dy, int n, int c, int hw, i
     const int inst = mode == VCG_NORM_INSTANCE;
     const long gp = inst ? hw : (long)n * hw;
     const int groups = inst ? n : 1;
-    const int slabs = (int)((gp + SPB - 1) / SPB);
+    const int slabs = (int)((gp + SPB - 1) / SPB), bpg = blocks_per_group(slabs, groups);
     float* part = (float*)ws;
     float* sums = part + (size_t)groups * slabs * c * 3;
-    norm_bwd_partial_bf16_kernel<<<groups * slabs, 256, 3 * 2048 * sizeof(float), stream>>>((const bf16x8*)x, (const bf16x8*)dy, c / 8, gp, slabs, inst,
-                                                                                             mean, invstd, gamma, beta, act, act_alpha, prelu_alpha, part);
+    norm_bwd_partial_bf16_kernel<<<groups * bpg, 256, 3 * 2048 * sizeof(float), stream>>>((const bf16x8*)x, (const bf16x8*)dy, c / 8, gp, slabs, inst,
+                                                                                           mean, invstd, gamma, beta, act, act_alpha, prelu_alpha, bpg, part);
     VCG_LAUNCH_CHECK();
     float* gsum = sums + (size_t)groups * c * 2;
-    norm_bwd_sums_bf16_kernel<<<groups * ceil_div(c, 64), 1024, 0, stream>>>(part, c, slabs, groups, sums, gsum);
+    norm_bwd_sums_bf16_kernel<<<groups * ceil_div(c, 64), 1024, 0, stream>>>(part, c, bpg, groups, sums, gsum);
     VCG_LAUNCH_CHECK();
     if (dgamma || dbeta || dprelu_alpha) {
         norm_bwd_params_bf16_kernel<<<ceil_div(c, 64), 64, 0, stream>>>(gsum, c, groups, dgamma, dbeta, dprelu_alpha);
