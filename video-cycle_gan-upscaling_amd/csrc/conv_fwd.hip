@@ -486,6 +486,64 @@ __global__ __launch_bounds__(256) void conv_smallm_kernel(const ConvParams p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// one output channel, stride 1 (the PatchGAN head: Conv2D(1, 4) on 512 channels): 0.5 GFLOP over 65 MB of input -- memory
+// work, not matrix work.  On the small-M MFMA kernel it occupies 4 of an MFMA's 32 rows and is bound by the wasted rows
+// (0.32 ms); here it is a plain FMA reduction: block = (image, output row, 64 columns), wave = a quarter of the input
+// channels, lane = column; the K shifted loads of a row overlap in L1; the four partial sums meet in LDS in a fixed order.
+// ------------------------------------------------------------------------------------------------
+template <int K>
+__global__ __launch_bounds__(256) void conv_cout1_kernel(const ConvParams p) {
+    __shared__ float red[4][64];
+    const int tid = threadIdx.x, xl = tid & 63;
+    const int cg = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int b = blockIdx.x;
+    const int seg = b % p.tiles_x; b /= p.tiles_x;
+    const int oy = b % p.oh;
+    const int n = b / p.oh;
+    const int ox = seg * 64 + xl, gx0 = ox - p.pad_left, gy0 = oy - p.pad_top;
+    const int hw = p.h * p.w_;
+    const vcg_rsrc rx = make_rsrc(p.x + (size_t)n * p.cin * hw, (size_t)p.cin * hw * sizeof(float));
+    unsigned coff[K];                                            // byte offset of (row 0, column gx0 + kx) or out of range
+#pragma unroll
+    for (int kx = 0; kx < K; ++kx) coff[kx] = (unsigned)(gx0 + kx) < (unsigned)p.w_ ? 4u * (unsigned)(gx0 + kx) : VCG_OOB;
+    float acc = 0.f;
+#pragma unroll 1                                                 // (unrolled x4 hipcc makes it 3x slower)
+    for (int c = cg; c < p.cin; c += 4) {
+        float wr[K * K];
+#pragma unroll
+        for (int t = 0; t < K * K; ++t) wr[t] = p.w[(p.flip ? K * K - 1 - t : t) * p.ws_t + c * p.ws_k];       // wave-uniform: scalar loads
+#pragma unroll
+        for (int ky = 0; ky < K; ++ky) {
+            const int gy = gy0 + ky;
+            const bool rok = (unsigned)gy < (unsigned)p.h;
+            const unsigned rbase = 4u * (unsigned)(c * hw + gy * p.w_);
+#pragma unroll
+            for (int kx = 0; kx < K; ++kx) acc += buf_load(rx, rok && coff[kx] != VCG_OOB ? rbase + coff[kx] : VCG_OOB) * wr[ky * K + kx];
+        }
+    }
+    red[cg][xl] = acc;
+    __syncthreads();
+    if (cg == 0 && ox < p.ow) {
+        float v = ((red[0][xl] + red[1][xl]) + (red[2][xl] + red[3][xl])) + (p.bias ? p.bias[0] : 0.f);
+        if (p.act == VCG_ACT_LRELU) v = v >= 0.f ? v : v * p.alpha;
+        else if (p.act == VCG_ACT_TANH) v = tanhf(v);
+        const size_t o = ((size_t)n * p.oh + oy) * p.ow + ox;
+        if (p.residual) v += p.residual[o];
+        p.y[o] = v;
+    }
+}
+
+template <int K>
+int launch_cout1(ConvParams p, hipStream_t st) {
+    p.tiles_x = ceil_div(p.ow, 64);
+    const long grid = (long)p.tiles_x * p.oh * p.n;
+    if (grid <= 0 || grid > 0x7fffffffL) return VCG_E_SHAPE;
+    hipLaunchKernelGGL(conv_cout1_kernel<K>, dim3((unsigned)grid), dim3(256), 0, st, p);
+    VCG_LAUNCH_CHECK();
+    return VCG_OK;
+}
+
 template <typename Kern>
 int launch_with_lds(Kern kern, int grid, size_t lds, const ConvParams& p, hipStream_t st) {
     if (lds > 64 * 1024) {
@@ -559,6 +617,12 @@ int vcg_internal_conv(const float* x, const float* w, float* y, int n, int cin, 
         if (kh == 9 && kw == 9 && !flip && pad_top == 4 && pad_left == 4 && oh == h && ow == wd && !p.prelu && !p.residual) {
             const int rc = vcg_internal_conv9_rowchain(x, w, y, n, cin, h, wd, cout, p.bias, p.act, ws_t, ws_m, ws_k, st);
             if (rc != VCG_E_UNSUPPORTED) return rc;
+        }
+        // one output channel on many input channels: the FMA reduction (the MFMA rows of the small-M kernel would be 7/8 padding)
+        if (cout == 1 && cin >= 64 && kh == kw && ws_m == 1 && !p.prelu && (size_t)cin * h * wd * 4 <= 0xFFFFFFE0u) {
+            if (kh == 3) return launch_cout1<3>(p, st);
+            if (kh == 4) return launch_cout1<4>(p, st);
+            if (kh == 5) return launch_cout1<5>(p, st);
         }
         if (kh == 9 && kw == 9) return launch_smallm<9, 9, 8>(p, st);
         if (kh == 4 && kw == 4) return launch_smallm<4, 4, 8>(p, st);
