@@ -7,11 +7,14 @@ namespace {
 constexpr int kMaxBatch = 64;
 constexpr int kBT = 8;  // batch rows per accumulator group
 
-// block: 64 output columns x 4 row-slices of the `in` dimension; partial sums reduced through LDS
-// in a fixed order (deterministic).  grid.x = ceil(out/64), grid.y = ceil(batch/kBT)
-__global__ __launch_bounds__(256) void dense_fwd_kernel(const float* x, const float* w, const float* bias, float* y,
-                                                        int batch, int in, int out) {
-    __shared__ float red[4][kBT][64];
+// partial sums reduced through LDS in a fixed order (deterministic).  grid.x = ceil(out/64), grid.y = ceil(batch/kBT)
+// block = 64 output columns x kSL slices of the input dimension (1024 threads); a thread keeps four weight loads in flight.  (The first
+// version had 4 slices and one load in flight: Dense_1 of simple_512, 2048 -> 1024 at batch 8, is 16 blocks of 512 serial loads each --
+// 0.27 ms for an 8 MB weight read.)
+constexpr int kSL = 16;
+__global__ __launch_bounds__(64 * kSL) void dense_fwd_kernel(const float* x, const float* w, const float* bias, float* y,
+                                                             int batch, int in, int out) {
+    __shared__ float red[kSL][kBT][64];
     const int col = threadIdx.x & 63, slice = threadIdx.x >> 6;
     const int o = blockIdx.x * 64 + col;
     const int b0 = blockIdx.y * kBT;
@@ -19,7 +22,18 @@ __global__ __launch_bounds__(256) void dense_fwd_kernel(const float* x, const fl
 #pragma unroll
     for (int b = 0; b < kBT; ++b) acc[b] = 0.f;
     if (o < out) {
-        for (int i = slice; i < in; i += 4) {
+        int i = slice;
+        for (; i + 3 * kSL < in; i += 4 * kSL) {
+            float wv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) wv[u] = w[(size_t)(i + u * kSL) * out + o];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int b = 0; b < kBT; ++b)
+                    if (b0 + b < batch) acc[b] += x[(size_t)(b0 + b) * in + i + u * kSL] * wv[u];
+        }
+        for (; i < in; i += kSL) {
             const float wv = w[(size_t)i * out + o];
 #pragma unroll
             for (int b = 0; b < kBT; ++b)
@@ -33,7 +47,9 @@ __global__ __launch_bounds__(256) void dense_fwd_kernel(const float* x, const fl
 #pragma unroll
         for (int b = 0; b < kBT; ++b) {
             if (b0 + b >= batch) continue;
-            float s = red[0][b][col] + red[1][b][col] + red[2][b][col] + red[3][b][col];
+            float s = 0.f;
+#pragma unroll
+            for (int k = 0; k < kSL; ++k) s += red[k][b][col];          // fixed order
             if (bias) s += bias[o];
             y[(size_t)(b0 + b) * out + o] = s;
         }
@@ -91,7 +107,7 @@ int vcg_dense_fwd(const float* x, const float* w_io, const float* bias, float* y
                   vcg_stream_t stream) {
     VCG_CHECK_PTR(x); VCG_CHECK_PTR(w_io); VCG_CHECK_PTR(y);
     if (batch <= 0 || in <= 0 || out <= 0) return VCG_E_SHAPE;
-    hipLaunchKernelGGL(dense_fwd_kernel, dim3(ceil_div(out, 64), ceil_div(batch, kBT)), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(dense_fwd_kernel, dim3(ceil_div(out, 64), ceil_div(batch, kBT)), dim3(64 * kSL), 0, (hipStream_t)stream,
                        x, w_io, bias, y, batch, in, out);
     VCG_LAUNCH_CHECK();
     return VCG_OK;
