@@ -226,6 +226,24 @@ def test_c_abi_argument_validation_without_a_gpu():
     assert need > 0 and lib.vcg_conv2d_bf16_wgrad(ctypes.byref(d), one, one, one, None, one, need - 1, None) == E_WORKSPACE
     need = lib.vcg_norm_act_bwd_bf16_workspace_bytes(2, 64, 64, 0)
     assert lib.vcg_norm_act_bwd_bf16(one, one, 2, 64, 64, 0, one, one, None, None, 0, 0.0, None, 1, one, None, None, None, one, need - 1, None) == E_WORKSPACE
+    # the entry points behind the other generators (resize / crop / concat / dropout) and the later bf16 kernels
+    assert lib.vcg_resize2d(None, one, 6, 8, 8, 2, 1, None) == E_NULL
+    assert lib.vcg_resize2d(one, one, 6, 8, 8, 0, 1, None) == E_SHAPE
+    assert lib.vcg_crop2d(one, one, 6, 8, 8, 4, 0, 8, 8, None) == E_SHAPE                  # the window leaves the source
+    assert lib.vcg_pad2d(one, one, 6, 8, 8, 1, 1, 8, 8, None) == E_SHAPE                   # the source does not fit the target
+    assert lib.vcg_copy_channels(one, one, 2, 3, 0, 227, 225, 3, 42, None) == E_SHAPE      # channel block past the destination
+    assert lib.vcg_dropout_fwd(one, one, one, 16, 1.0, 1, None, None) == E_SHAPE           # rate must be in [0, 1)
+    assert lib.vcg_dropout_bwd(one, None, one, 16, 0.1, None) == E_NULL
+    assert lib.vcg_counter_inc(None, None) == E_NULL
+    d9 = L.ConvDesc(1, 256, 8, 9, 3, 8, 9, 9, 9, 1, 4, 4)                                   # odd width
+    need = lib.vcg_conv9x9_to3_bf16_wgrad_workspace_bytes(ctypes.byref(d9))
+    assert need > 0 and lib.vcg_conv9x9_to3_bf16_wgrad(ctypes.byref(d9), one, one, one, one, need, None) == E_UNSUPPORTED
+    d9 = L.ConvDesc(1, 256, 8, 8, 3, 8, 8, 9, 9, 1, 4, 4)
+    assert lib.vcg_conv9x9_to3_bf16_wgrad(ctypes.byref(d9), one, one, one, one, 16, None) == E_WORKSPACE
+    dt = L.ConvDesc(1, 64, 8, 8, 256, 8, 8, 3, 3, 1, 0, 0)                                  # a transposed convolution with strides 1
+    assert lib.vcg_conv_transpose2d_nhwc_bf16_fwd(ctypes.byref(dt), one, one, None, 0, 0.0, one, None) == E_UNSUPPORTED
+    d17 = L.ConvDesc(1, 64, 8, 8, 64, 8, 8, 1, 7, 1, 0, 3)                                  # 1xk / kx1 kernels (inception-resnet) have a weight-gradient plan
+    assert lib.vcg_conv2d_wgrad_workspace_bytes(ctypes.byref(d17)) > lib.vcg_channel_sum_workspace_bytes(1, 64, 64)
     for code in (E_NULL, E_SHAPE, E_UNSUPPORTED, E_WORKSPACE):
         assert lib.vcg_error_string(code) and lib.vcg_error_string(code) != lib.vcg_error_string(0)
     # and the Python shim turns them into exceptions
