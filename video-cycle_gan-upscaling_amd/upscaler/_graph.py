@@ -391,7 +391,9 @@ def build_model(inputs, outputs, name="model", seed=7):
                         import zlib
                         y = rt.empty(*x_.shape)
                         mask = torch.empty(x_.shape, dtype=torch.uint8, device=rt.device)
-                        seed = (zlib.crc32(attrs["name"].encode()) << 20) ^ ((self._seed * 0x9E3779B1) & 0xFFFFFFFFFFFF)
+                        # per layer, per model seed and per data-parallel rank (each rank drops its own shard independently)
+                        rank = torch.distributed.get_rank() if torch.distributed.is_available() and torch.distributed.is_initialized() else 0
+                        seed = (zlib.crc32(attrs["name"].encode()) << 20) ^ ((self._seed * 0x9E3779B1) & 0xFFFFFFFFFFFF) ^ (rank << 52)
                         L.check(rt.lib.vcg_dropout_fwd(x_.data_ptr(), y.data_ptr(), mask.data_ptr(), x_.numel(), attrs["rate"], seed,
                                                        self._drop_step.data_ptr(), rt.stream), "vcg_dropout_fwd")
                         vals[i], tape[i] = y, mask
