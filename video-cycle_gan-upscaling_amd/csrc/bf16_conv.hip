@@ -420,14 +420,14 @@ __global__ __launch_bounds__(V2_NT, 1) void conv3x3_c64_bf16_v2_kernel(C3Params 
     for (int k = 0; k < V2_NDMA; ++k) {
         const int sl = k * V2_NT + tid, P = sl >> 3, row = P / V2_HC, col = P - row * V2_HC;
         const int cs = (sl & 7) ^ ((col >> 1) & 7);                                // stored chunk (sl & 7) holds source chunk cs
-        dma_c[k] = (unsigned)((row * p.w_ + col) * 128 + cs * 16);
+        dma_c[k] = (unsigned)(row * p.w_ + col) * 128u + (unsigned)(cs * 16);
         if ((k & 3) == 0) dma_colp[k >> 2] = 0;
         dma_colp[k >> 2] |= (unsigned)(sl < V2_CHUNKS ? col : 255) << (8 * (k & 3));     // 255: the slots past the tile (round 19, lanes 32-63)
     }
     auto locate = [&](int tile, bool live) {
         const int txi = tile % p.tiles_x, t2 = tile / p.tiles_x, tyi = t2 % p.tiles_y, img = t2 / p.tiles_y;
         const int y0 = tyi * V2_TR - 1, x0 = txi * V2_TC - 1;
-        return TileSrc{(unsigned)((y0 * p.w_ + x0) * 128), x0, make_rsrc((const unsigned char*)p.x + img * img_bytes, (unsigned long)(live ? img_bytes : 0))};
+        return TileSrc{(unsigned)(y0 * p.w_ + x0) * 128u, x0, make_rsrc((const unsigned char*)p.x + img * img_bytes, (unsigned long)(live ? img_bytes : 0))};
     };
     auto dma = [&](const TileSrc& ts, int buf, int k) {
         if (k == V2_NDMA - 1 && wv != 0) return;                 // wave-uniform
@@ -469,7 +469,7 @@ __global__ __launch_bounds__(V2_NT, 1) void conv3x3_c64_bf16_v2_kernel(C3Params 
     };
     auto out_off = [&](const OutPos& o, int n, int q) {
         const int gy = o.gy0 + n;
-        unsigned off = (unsigned)((gy * p.w_ + o.gx) * 128 + (coh * 32 + 16 * q + 8 * hh) * 2);
+        unsigned off = (unsigned)(gy * p.w_ + o.gx) * 128u + (unsigned)((coh * 32 + 16 * q + 8 * hh) * 2);
         asm volatile("" : "+v"(off));                            // a select, not a branch around the arithmetic (it would split the schedule)
         return gy < p.h && o.okx ? off : VCG_OOB;
     };

@@ -245,7 +245,7 @@ __global__ __launch_bounds__(256, 1) void gconv_lds_bf16_kernel(const GlParams p
         const int pli = c / cpp, cc = c - pli * cpp;
         const int iy = p.isy * (sc.y0 + p.pl[pli].dy0 + row) + p.pl[pli].py, ix = p.isx * (sc.x0 + p.pl[pli].dx0 + col) + p.pl[pli].px;
         const bool ok = live && sl < CH16 && (unsigned)iy < (unsigned)p.ih && (unsigned)ix < (unsigned)p.iw;
-        unsigned off = (unsigned)(((iy * p.iw + ix) * p.kch + cc * 64) * 2 + cs * 16);
+        unsigned off = ((unsigned)(iy * p.iw + ix) * (unsigned)p.kch + (unsigned)(cc * 64)) * 2u + (unsigned)(cs * 16);      // < 4 GiB: unsigned arithmetic
         asm volatile("" : "+v"(off));                            // a select, not a branch around the arithmetic
         off = ok ? off : VCG_OOB;
         const vcg_rsrc rx = make_rsrc((const unsigned char*)p.x + sc.img * img_in, (unsigned long)img_in);
@@ -326,7 +326,7 @@ __global__ __launch_bounds__(256, 1) void gconv_lds_bf16_kernel(const GlParams p
                 for (int n = 0; n < GL_TR; ++n) {
                     const int ly = cur.ty * GL_TR + n, oy = ly * p.osy + p.ooy;
                     const bool ok = ly < p.loh && lx < p.low && oy < p.oh && ox < p.ow && mtile < p.mblocks;
-                    unsigned off = (unsigned)(((oy * p.ow + ox) * p.mch + co) * 2);
+                    unsigned off = ((unsigned)(oy * p.ow + ox) * (unsigned)p.mch + (unsigned)co) * 2u;
                     asm volatile("" : "+v"(off));
                     off = ok ? off : VCG_OOB;
                     float v[8];

@@ -94,12 +94,12 @@ __global__ __launch_bounds__(256, 1) void wgrad9x9_c256to3_bf16_kernel(W9Params 
                 const int cs = (((pos >> 2) ^ (P & 3)) << 2) | (pos & 3);          // stored position pos holds source chunk cs
                 const int gy = y0 + row, gx = x0 + col;
                 ok = gy < p.h && gx < p.w_;
-                off = (unsigned)((gy * p.w_ + gx) * 512 + mh * 256 + cs * 16);
+                off = (unsigned)(gy * p.w_ + gx) * 512u + (unsigned)(mh * 256 + cs * 16);
             } else {                                                    // dz halo: two pixels per 16 bytes (w is even: a pair never straddles a row)
                 const int sd = s - W9_XB / 16, row = (2 * sd) / W9_DC, col = 2 * sd - row * W9_DC;
                 const int gy = y0 - 4 + row, gx = x0 - 4 + col;
                 ok = sd < W9_DYB / 16 && (unsigned)gy < (unsigned)p.h && (unsigned)gx < (unsigned)p.w_;
-                off = (unsigned)((gy * p.w_ + gx) * 8);
+                off = (unsigned)(gy * p.w_ + gx) * 8u;
             }
             asm volatile("" : "+v"(off));
             off = ok ? off : VCG_OOB;
