@@ -631,6 +631,8 @@ GCONV_CASES = [
     (64, 64, 3, 1, "same", 8, 64, 64),         # 64 output channels: a ragged 128-channel group (two of the four waves compute nothing)
     (64, 192, 3, 1, "same", 4, 64, 64),        # 192 = one full group + one ragged
     (64, 128, 4, 2, 1, 4, 128, 96),            # stride-2 forward through the four parity planes (PatchGAN block 2), 64-channel gradient groups
+    (128, 128, 3, 1, "same", 5, 67, 45),       # odd sizes on the LDS kernel, two input chunks
+    (128, 128, 3, 2, "same", 7, 75, 83),       # stride 2 on odd sizes: TF-SAME pads (1,1), parity planes of unequal extent
 ]
 
 
