@@ -71,9 +71,22 @@ __global__ void f32_nchw_to_bf16_nhwc_kernel(const float* __restrict__ x, __bf16
             tile[cc][pp] = v;
         }
         __syncthreads();
-        for (int e = threadIdx.x; e < 64 * 64; e += blockDim.x) {
-            const int pp = e >> 6, cc = e & 63;
-            if (c0 + cc < c && p0 + pp < hw) y[((long)img * hw + p0 + pp) * c + c0 + cc] = (__bf16)tile[cc][pp];
+        if ((c & 7) == 0) {
+            // 16-byte stores: a thread packs 8 consecutive channels of one pixel (8 lanes = one pixel's 128 bytes)
+            for (int e = threadIdx.x; e < 64 * 8; e += blockDim.x) {
+                const int pp = e >> 3, ch = (e & 7) * 8;
+                if (c0 + ch < c && p0 + pp < hw) {
+                    bf16x8 v;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = (__bf16)tile[ch + j][pp];
+                    *(bf16x8*)(y + ((long)img * hw + p0 + pp) * c + c0 + ch) = v;
+                }
+            }
+        } else {
+            for (int e = threadIdx.x; e < 64 * 64; e += blockDim.x) {
+                const int pp = e >> 6, cc = e & 63;
+                if (c0 + cc < c && p0 + pp < hw) y[((long)img * hw + p0 + pp) * c + c0 + cc] = (__bf16)tile[cc][pp];
+            }
         }
         __syncthreads();
     }
@@ -83,11 +96,24 @@ __global__ void bf16_nhwc_to_f32_nchw_kernel(const __bf16* __restrict__ x, float
     __shared__ float tile[64][65];
     const int p0 = blockIdx.x * 64, img = blockIdx.y;
     for (int c0 = 0; c0 < c; c0 += 64) {
-        for (int e = threadIdx.x; e < 64 * 64; e += blockDim.x) {
-            const int pp = e >> 6, cc = e & 63;
-            float v = 0.f;
-            if (c0 + cc < c && p0 + pp < hw) v = (float)x[((long)img * hw + p0 + pp) * c + c0 + cc];
-            tile[cc][pp] = v;
+        if ((c & 7) == 0) {
+            // 16-byte loads: a thread takes 8 consecutive channels of one pixel
+            for (int e = threadIdx.x; e < 64 * 8; e += blockDim.x) {
+                const int pp = e >> 3, ch = (e & 7) * 8;
+                bf16x8 v;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = (__bf16)0.f;
+                if (c0 + ch < c && p0 + pp < hw) v = *(const bf16x8*)(x + ((long)img * hw + p0 + pp) * c + c0 + ch);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) tile[ch + j][pp] = (float)v[j];
+            }
+        } else {
+            for (int e = threadIdx.x; e < 64 * 64; e += blockDim.x) {
+                const int pp = e >> 6, cc = e & 63;
+                float v = 0.f;
+                if (c0 + cc < c && p0 + pp < hw) v = (float)x[((long)img * hw + p0 + pp) * c + c0 + cc];
+                tile[cc][pp] = v;
+            }
         }
         __syncthreads();
         for (int e = threadIdx.x; e < 64 * 64; e += blockDim.x) {
