@@ -222,11 +222,12 @@ __global__ void wgrad3x3_c64_reduce_kernel(const float* __restrict__ ws, int nbl
     const int dyi = idx / G_WAVE_FLOATS, off = idx - dyi * G_WAVE_FLOATS;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     int b = 0;
-    for (; b + 3 < nblocks; b += 4) {
-        s0 += ws[((long)(b + 0) * 3 + dyi) * G_WAVE_FLOATS + off];
-        s1 += ws[((long)(b + 1) * 3 + dyi) * G_WAVE_FLOATS + off];
-        s2 += ws[((long)(b + 2) * 3 + dyi) * G_WAVE_FLOATS + off];
-        s3 += ws[((long)(b + 3) * 3 + dyi) * G_WAVE_FLOATS + off];
+    for (; b + 7 < nblocks; b += 8) {                                   // eight partial blocks in flight per thread, fixed order
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = ws[((long)(b + u) * 3 + dyi) * G_WAVE_FLOATS + off];
+        s0 += v[0]; s1 += v[1]; s2 += v[2]; s3 += v[3];
+        s0 += v[4]; s1 += v[5]; s2 += v[6]; s3 += v[7];
     }
     for (; b < nblocks; ++b) s0 += ws[((long)b * 3 + dyi) * G_WAVE_FLOATS + off];
     // raw offset -> tile (dx, ci half, co half), register e, lane l;  D[row][col]: row = (e&3) + 8*(e>>2) + 4*(l>>5), col = l&31
@@ -240,7 +241,15 @@ __global__ __launch_bounds__(1024) void wgrad3x3_c64_bias_reduce_kernel(const fl
     __shared__ float red[16][64];
     const int c = threadIdx.x & 63, g = threadIdx.x >> 6, rows = nblocks * 4;
     float s = 0.f;
-    for (int b = g; b < rows; b += 16) s += wsb[(long)b * 64 + c];
+    int b = g;
+    for (; b + 48 < rows; b += 64) {                                    // four rows in flight per thread (a single workgroup: latency-bound otherwise)
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = wsb[(long)(b + 16 * u) * 64 + c];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) s += v[u];
+    }
+    for (; b < rows; b += 16) s += wsb[(long)b * 64 + c];
     red[g][c] = s;
     __syncthreads();
     if (g == 0) {
