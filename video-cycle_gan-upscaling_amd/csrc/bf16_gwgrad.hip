@@ -240,11 +240,12 @@ __global__ void gwgrad_reduce_kernel(GwReduce p) {
     if (idx >= per_slab) return;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     int b = 0;
-    for (; b + 3 < p.slabs; b += 4) {
-        s0 += p.ws[(long)(b + 0) * per_slab + idx];
-        s1 += p.ws[(long)(b + 1) * per_slab + idx];
-        s2 += p.ws[(long)(b + 2) * per_slab + idx];
-        s3 += p.ws[(long)(b + 3) * per_slab + idx];
+    for (; b + 7 < p.slabs; b += 8) {                                   // eight slabs in flight per thread, fixed order
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = p.ws[(long)(b + u) * per_slab + idx];
+        s0 += v[0]; s1 += v[1]; s2 += v[2]; s3 += v[3];
+        s0 += v[4]; s1 += v[5]; s2 += v[6]; s3 += v[7];
     }
     for (; b < p.slabs; ++b) s0 += p.ws[(long)b * per_slab + idx];
     // idx -> (pair, wave, tile (i, cih, coh), register e, lane l);  D[row][col]: row = (e&3) + 8*(e>>2) + 4*(l>>5), col = l&31
@@ -265,7 +266,19 @@ __global__ void gwgrad_bias_reduce_kernel(GwReduce p) {
     if (co >= p.cout) return;
     const int cob = co >> 6, c = co & 63;
     float s = 0.f;
-    for (int b = 0; b < p.slabs; ++b) {
+    int b = 0;
+    for (; b + 7 < p.slabs; b += 8) {                                   // eight slabs in flight (one thread per channel: latency-bound otherwise)
+        float v[8][2];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const float* bo = p.wsb + (((long)(b + u) * p.co_blocks + cob) * 2) * 64;
+            v[u][0] = bo[c];
+            v[u][1] = bo[64 + c];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u][0] + v[u][1];
+    }
+    for (; b < p.slabs; ++b) {
         const float* bo = p.wsb + (((long)b * p.co_blocks + cob) * 2) * 64;
         s += bo[c] + bo[64 + c];
     }
