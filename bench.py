@@ -154,13 +154,15 @@ def run_c5(args):
     inf = G.to_inference_bf16()
     g1 = torch.Generator().manual_seed(1234)
     x = PD.frames_u8_to_device(torch.randint(0, 256, (B, h, w, 3), generator=g1, dtype=torch.uint8))
-    inf.capture(B, h, w)
+    step = inf.forward if args.no_graph else inf.replay       # --no-graph: eager launches (the PMC passes of scripts/pmc_step.sh)
+    if not args.no_graph:
+        inf.capture(B, h, w)
     for _ in range(args.warmup):
-        inf.replay(x)
+        step(x)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        inf.replay(x)
+        step(x)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
 
@@ -195,7 +197,7 @@ def run_c5(args):
         "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
         "config": {"workload": "C5: make_upscaler_orig((%d,%d,3),k=3,x2,res=%d).predict, BN folded, bf16 NHWC activations, fp32 accumulate, "
                                "batch %d, one hipGraph replay per batch" % (2 * h, 2 * w, args.res_blocks, B), "global_batch": B,
-                   "frame": "%dx%d->%dx%d" % (h, w, 2 * h, 2 * w), "parallelism": "dp1", "launch": "hipGraph replay"},
+                   "frame": "%dx%d->%dx%d" % (h, w, 2 * h, 2 * w), "parallelism": "dp1", "launch": "eager" if args.no_graph else "hipGraph replay"},
         "roofline": {"bound": "hbm", "kernel": kname + " (64->64 3x3 trunk convolution, bf16 NHWC)", "achieved": round(ach, 1),
                      "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": traffic,
                      "traffic_source": rec and rec.get("source"),
@@ -211,8 +213,8 @@ def run_c5(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", default="c2", choices=["c2", "c5"], help="c2: the train step (headline); c5: inference-only generator, bf16, hipGraph")
     ap.add_argument("--batch", type=int, default=0, help="frames per GPU (default 8; 32 for --config c5)")
     ap.add_argument("--lr-size", type=int, default=256, help="low-res frame edge (output is 2x)")

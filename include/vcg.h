@@ -104,6 +104,20 @@ int vcg_norm_finalize(const float* mean, const float* var, const float* gamma, c
                       int rows, float eps, float* scale, float* shift, float* invstd,
                       float* moving_mean, float* moving_var, float momentum, int unbiased_count,
                       vcg_stream_t stream);
+/* out[ch] = scale * sum over rec of part[rec][ch] (part fp32 [nrec][c]), in double and in a fixed order: the tail of every kernel that
+ * leaves per-workgroup records instead of using atomics */
+int vcg_sum_records(const float* part, int nrec, int c, float scale, float* out, vcg_stream_t stream);
+/* inference-mode BatchNormalization folded into the epilogue of the convolution in front of it (model.py:19-20 with learning phase 0):
+ * scale = gamma * rsqrt(moving_var + eps), shift = (bias - moving_mean) * scale + beta; bias / gamma / beta may be NULL (0 / 1 / 0) */
+int vcg_bn_fold(const float* bias, const float* moving_mean, const float* moving_var, const float* gamma, const float* beta, int c, float eps,
+                float* scale, float* shift, vcg_stream_t stream);
+/* the same from partial records written by a convolution's epilogue (vcg_epilogue_bf16.stats, vcg_conv2d_nhwc_bf16_fwd_stats):
+ * part fp32 [groups][nrec][2][c] = per-record sums and sums of squares over `count` values per group and channel in all; groups = 1
+ * (batch statistics; only then are the moving averages updated) or n (instance norm).  Writes mean, scale, shift, invstd [groups*c].
+ * One launch in place of vcg_norm_stats* + vcg_norm_finalize; the records are added in a fixed order (deterministic). */
+int vcg_norm_finalize_partials(const float* part, int nrec, int groups, int c, double count, const float* gamma, const float* beta,
+                               float eps, float* mean, float* scale, float* shift, float* invstd, float* moving_mean,
+                               float* moving_var, float momentum, int unbiased_count, vcg_stream_t stream);
 /* y = act(x*scale + shift) + residual ; scale/shift indexed [c] (rows==1) or [n*c] */
 int vcg_norm_act_fwd(const float* x, int n, int c, int hw, const float* scale, const float* shift,
                      int per_sample, int act, float act_alpha, const float* prelu_alpha,
@@ -242,7 +256,16 @@ typedef struct vcg_epilogue_bf16 {
     float act_alpha;
     const void* prelu_alpha;
     const void* residual;
+    /* statistics of the stored output for the normalisation BEHIND the convolution (training-mode BatchNormalization, model.py:20,23,284;
+     * instance norm): stats_mode VCG_STATS_NONE, or VCG_STATS_BATCH / VCG_STATS_INSTANCE with `stats` = fp32
+     * [groups][records][2][cout] (groups = 1 / n; records = vcg_conv2d_bf16_stats_records): per-record sums and sums of squares that
+     * vcg_norm_finalize_partials adds up in a fixed order.  Replaces the vcg_norm_stats_bf16 pass over the output. */
+    void* stats;
+    int32_t stats_mode;
 } vcg_epilogue_bf16;
+#define VCG_STATS_NONE 0
+#define VCG_STATS_BATCH 1
+#define VCG_STATS_INSTANCE 2
 
 /* fp32 kernel -> packed bf16.  out[tap'][i][j] (j contiguous) = transpose ? w[tap][j][i] : w[tap][i][j], with
  * tap' = flip ? taps-1-tap : tap.  Conv2D forward from Keras' (kh,kw,in,out): a=out, b=in, transpose=1, flip=0;
@@ -260,6 +283,9 @@ int vcg_bf16_nhwc_to_f32_nchw(const void* x, void* y, int32_t n, int32_t c, int3
  * other shapes return VCG_E_UNSUPPORTED. */
 int vcg_conv2d_bf16_fwd(const vcg_conv_desc* d, const void* x, const void* w_packed, void* y, const vcg_epilogue_bf16* ep,
                         hipStream_t stream);
+/* records per group the convolution writes into ep->stats for this shape and mode (> 0), or a negative VCG_E_* when its epilogue
+ * cannot produce statistics for it (the caller then runs vcg_norm_stats_bf16 on the output) */
+int vcg_conv2d_bf16_stats_records(const vcg_conv_desc* d, int32_t stats_mode);
 
 /* Conv2DTranspose(strides=2, padding='same') forward on bf16 NHWC (+ fused LeakyReLU: upsampling_block,
  * upscaling/upscaler/model.py:70-75).  w_packed: [tap][out][in] (vcg_pack_conv_kernel_bf16(w, 9, out, in, 0, 0) from
@@ -290,6 +316,12 @@ int vcg_pack_conv9x9_3ch_bf16(const void* w, int32_t cout, int32_t dgrad, void* 
  * (upsampling_block, model.py:73); dx is then multiplied by its derivative, i.e. it is the gradient in front of the activation. */
 int vcg_conv9x9_to3_bf16_dgrad(const vcg_conv_desc* d, const void* dy, const void* wfrag, const void* y_prev, float lrelu_slope, void* dx,
                                hipStream_t stream);
+/* the same, also leaving per-channel sums of the stored dx as fp32 records [vcg_conv9x9_to3_bf16_dgrad_chsum_records(d)][cin]: added up by
+ * vcg_sum_records they are the bias gradient of the layer that produced the convolution's input (upsampling_block's Conv2DTranspose,
+ * model.py:72) -- no separate pass over dx */
+int vcg_conv9x9_to3_bf16_dgrad_chsum_records(const vcg_conv_desc* d);
+int vcg_conv9x9_to3_bf16_dgrad_chsum(const vcg_conv_desc* d, const void* dy, const void* wfrag, const void* y_prev, float lrelu_slope, void* dx,
+                                     float* records, hipStream_t stream);
 int vcg_conv9x9_from3_bf16_fwd(const vcg_conv_desc* d, const void* x, const void* wfrag, const void* bias, const void* prelu_alpha,
                                void* y, hipStream_t stream);
 
@@ -332,6 +364,14 @@ int vcg_pack_conv_frag_bf16(const float* w, int taps, int mdim, int kdim, int mo
 /* y = act(conv(x) + bias), x / y bf16 NHWC, bias fp32 [cout] or NULL, act VCG_ACT_NONE / VCG_ACT_LRELU */
 int vcg_conv2d_nhwc_bf16_fwd(const vcg_conv_desc* d, const void* x, const void* wfrag, const float* bias, int act, float act_alpha,
                              void* y, hipStream_t stream);
+/* the same without activation, also leaving per-tile statistics of the stored output for the normalisation behind the layer
+ * (model.py:840-841 and the PatchGAN blocks in training mode): stats fp32 [n][records][2][cout], records per image =
+ * vcg_conv2d_nhwc_bf16_stats_records(d, VCG_STATS_INSTANCE) (one per 8x32-pixel output tile; ..._BATCH returns n times that) -- read by
+ * vcg_norm_finalize_partials as [1][n*records] (batch statistics) or [n][records] (instance norm).  A negative record count means the
+ * tiled kernel does not serve the shape: use vcg_conv2d_nhwc_bf16_fwd + vcg_norm_stats_bf16. */
+int vcg_conv2d_nhwc_bf16_stats_records(const vcg_conv_desc* d, int stats_mode);
+int vcg_conv2d_nhwc_bf16_fwd_stats(const vcg_conv_desc* d, const void* x, const void* wfrag, const float* bias, void* y, float* stats,
+                                   hipStream_t stream);
 /* Conv2DTranspose(k, strides 2, 'same') + bias + LeakyReLU (model.py:72-73) on bf16 NHWC as the data gradient of the stride-2 convolution its
  * kernel is: d describes the transposed layer (cin, h, w -> cout, oh, ow; pads = the 'same' crop), wfrag =
  * vcg_pack_conv_frag_bf16(kernel (kh,kw,out,in), k*k, mdim = cout, kdim = cin, mode 1) */

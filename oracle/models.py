@@ -98,19 +98,22 @@ def init_upscaler_orig(output_image_shape, kernel_size=5, filters=64, upscale_fa
     return w
 
 
-def upscaler_orig_forward(w, x_nhwc, training, res_block_num, upscale_factor, taps=None, norm="batch", trunk_bf16=False, tail_bf16=False):
+def upscaler_orig_forward(w, x_nhwc, training, res_block_num, upscale_factor, taps=None, norm="batch", trunk_bf16=False, tail_bf16=False,
+                          fold_inference=True):
     """x_nhwc: [N,h,w,3] -> ([N,h*f,w*f,3], bn_updates).  ``training`` selects batch vs moving BN
     statistics (Keras learning phase: predict=0, train_on_batch=1).  ``taps`` (optional dict)
     receives named NCHW intermediates for kernel-level parity tests.  ``trunk_bf16`` marks the tensors the
     product's ``trunk_dtype='bf16'`` mode stores in bf16 (values and gradients; keras_ops.bf16_*); ``tail_bf16`` adds those of
-    ``'bf16+tail'`` (up-sampling block and final/conv)."""
+    ``'bf16+tail'`` (up-sampling block and final/conv).  ``fold_inference``: in learning phase 0 the product's bf16 trunk applies the
+    BatchNormalization in the convolution's epilogue, so the convolution's own output is never stored (no rounding there)."""
     upd = OrderedDict()
     st = K.bf16_store if trunk_bf16 else (lambda v: v)
     rf = K.bf16_round_fwd if trunk_bf16 else (lambda v: v)
     rg = K.bf16_round_grad if trunk_bf16 else (lambda v: v)
 
     def tconv(x, name):          # trunk convolution: bf16 copy of the fp32 master kernel, output (+bias) stored in bf16
-        return st(K.conv2d(x, rf(w[name + "/kernel"]), w[name + "/bias"], 1, "same"))
+        y = K.conv2d(x, rf(w[name + "/kernel"]), w[name + "/bias"], 1, "same")
+        return y if (fold_inference and not training and norm == "batch") else st(y)
 
     def bn(x, name):
         if norm == "instance":          # north_star extension (no reference counterpart)

@@ -808,3 +808,112 @@ def test_all_bf16_train_step_at_c4_frame_size(rt):
     assert e < 2e-2                                # bf16 storage through 2 blocks + tail (3e-2 bound of the 9-block inference test)
     for a, b in zip(lb, lf):
         assert abs(a - b) < 3e-2 * (max(abs(v) for v in lf) + 1e-6), (lb, lf)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# statistics of the normalisation behind a convolution, out of the convolution's epilogue (no separate pass over its output)
+# ---------------------------------------------------------------------------------------------------------------
+def _check_partials(rt, y_nhwc, stats, instance, layer_name, gamma=None, beta=None, tol=2e-5):
+    """vcg_norm_finalize_partials on the records `stats` against fp64 statistics of the STORED bf16 tensor y"""
+    from upscaler import _engine as E, _lib as L
+    buf, nrec = stats
+    n, h, w, c = y_nhwc.shape
+    rows = n if instance else 1
+    cnt = h * w if instance else n * h * w
+    mean, scale, shift, invstd = (rt.empty(rows * c) for _ in range(4))
+    mm, mv = E.filled_like(rt, rt.empty(c), 0.25), E.filled_like(rt, rt.empty(c), 2.0)
+    eps = E.IN_EPS if instance else E.BN_EPS
+    L.check(rt.lib.vcg_norm_finalize_partials(buf.data_ptr(), nrec, rows, c, float(cnt), gamma.data_ptr() if gamma is not None else None,
+                                              beta.data_ptr() if beta is not None else None, eps, mean.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+                                              invstd.data_ptr(), None if instance else mm.data_ptr(), None if instance else mv.data_ptr(), 0.99,
+                                              0 if instance else cnt, rt.stream), "vcg_norm_finalize_partials")
+    yd = y_nhwc.cpu().double()
+    dims = (1, 2) if instance else (0, 1, 2)
+    m_ref = yd.mean(dims).reshape(-1)
+    v_ref = yd.var(dims, unbiased=False).reshape(-1)
+    is_ref = 1.0 / torch.sqrt(v_ref + eps)
+    sd = float(v_ref.sqrt().max())
+    e_m = float((mean.cpu().double() - m_ref).abs().max()) / sd
+    e_is = rel_err(invstd, is_ref)
+    ga = gamma.cpu().double() if gamma is not None else torch.ones(c, dtype=torch.float64)
+    be = beta.cpu().double() if beta is not None else torch.zeros(c, dtype=torch.float64)
+    sc_ref = (ga.repeat(rows) * is_ref)
+    e_sc = rel_err(scale, sc_ref)
+    e_sh = float((shift.cpu().double() - (be.repeat(rows) - m_ref * sc_ref)).abs().max()) / float(1.0 + (m_ref * sc_ref).abs().max())
+    report("stats epilogue %s %s n=%d %dx%dx%d: mean=%.1e invstd=%.1e scale=%.1e shift=%.1e (records per group %d)"
+           % (layer_name, "instance" if instance else "batch", n, h, w, c, e_m, e_is, e_sc, e_sh, nrec))
+    assert e_m < tol and e_is < tol and e_sc < tol and e_sh < tol, (e_m, e_is, e_sc, e_sh)
+    if not instance:            # moving averages: momentum 0.99, Bessel-corrected variance (the 4-D Keras path)
+        mm_ref = 0.25 * 0.99 + m_ref * 0.01
+        mv_ref = 2.0 * 0.99 + v_ref * cnt / (cnt - 1) * 0.01
+        assert rel_err(mm, mm_ref) < 1e-6 and rel_err(mv, mv_ref) < 1e-6
+
+
+@pytest.mark.parametrize("n,h,w,instance", [(2, 16, 32, False), (1, 13, 45, False), (3, 40, 72, True), (2, 5, 7, True), (16, 81, 97, False),
+                                             (10, 100, 100, True), (3, 200, 300, False), (8, 256, 256, False)])
+def test_conv3x3_c64_bf16_stats_epilogue(rt, n, h, w, instance):
+    """Conv3x3Bf16.forward_stats: the output is bit-identical to forward's, and the records finalize to the mean / variance of the
+    stored tensor (ragged tiles, tiles smaller than the image, several tiles per workgroup, per-image statistics)"""
+    from upscaler import _engine as E
+    layer = E.Conv3x3Bf16("c")
+    ps = E.ParamStore()
+    layer.declare(ps)
+    ps.materialize(rt)
+    layer.bind(rt, ps)
+    g = torch.Generator().manual_seed(n * 100 + h + w)
+    ps.set_weights({"c/kernel": (torch.randn(3, 3, 64, 64, generator=g) * 0.06).numpy(), "c/bias": (torch.randn(64, generator=g) * 0.7).numpy()})
+    x = _to_nhwc_bf16(rt, (torch.randn(n, 64, h, w, generator=g) + 0.3).to(rt.device))
+    y0, _ = layer.forward(x)
+    y1, _, st = layer.forward_stats(x, instance)
+    assert st is not None
+    assert torch.equal(y0.view(torch.int16), y1.view(torch.int16))
+    gamma = (torch.rand(64, generator=g) + 0.5).to(rt.device)
+    beta = torch.randn(64, generator=g).to(rt.device)
+    _check_partials(rt, y1, st, instance, "conv3x3 v2", None if instance else gamma, None if instance else beta)
+    # deterministic
+    y2, _, st2 = layer.forward_stats(x, instance)
+    assert torch.equal(st[0], st2[0])
+
+
+GSTAT_CASES = [
+    # cin, cout, k, stride, padding, n, h, w, instance
+    (64, 128, 4, 2, 1, 4, 128, 96, True),        # PatchGAN block 2 (parity planes)
+    (128, 256, 4, 2, 1, 4, 128, 128, True),      # block 3
+    (256, 512, 4, 1, 1, 2, 70, 50, True),        # block 4, ragged tiles
+    (256, 512, 4, 1, 1, 2, 70, 50, False),       # the same with batch statistics (norm='batch')
+    (64, 128, 3, 2, "same", 4, 128, 128, False),  # simple_512 block 2
+    (128, 128, 3, 1, "same", 5, 67, 45, False),  # odd sizes, two input chunks
+    (64, 192, 3, 1, "same", 4, 64, 64, False),   # a ragged 128-channel group
+]
+
+
+@pytest.mark.parametrize("cin,cout,k,stride,padding,n,h,w,instance", GSTAT_CASES)
+def test_generic_conv_bf16_stats_epilogue(rt, cin, cout, k, stride, padding, n, h, w, instance):
+    from upscaler import _engine as E
+    layer = E.Conv2DBf16("c", cin, cout, k, stride, padding)
+    ps = E.ParamStore()
+    layer.declare(ps)
+    ps.materialize(rt)
+    layer.bind(rt, ps)
+    g = torch.Generator().manual_seed(cin + cout + k + h)
+    ps.set_weights({"c/kernel": (torch.randn(k, k, cin, cout, generator=g) * (2.0 / (k * k * cin)) ** 0.5).numpy(),
+                    "c/bias": (torch.randn(cout, generator=g) * 0.5).numpy()})
+    x = _to_nhwc_bf16(rt, torch.randn(n, cin, h, w, generator=g).to(rt.device))
+    y0, _ = layer.forward(x)
+    y1, _, st = layer.forward_stats(x, instance)
+    assert st is not None, "the LDS-tiled kernel serves this shape"
+    assert torch.equal(y0.view(torch.int16), y1.view(torch.int16))
+    _check_partials(rt, y1, st, instance, "gconv_lds %d->%d k%d s%d" % (cin, cout, k, stride))
+
+
+def test_stats_epilogue_falls_back_when_unsupported(rt):
+    """a shape the tiled kernels do not serve (too few tiles) reports no records; the layer then returns stats=None"""
+    from upscaler import _engine as E
+    layer = E.Conv2DBf16("c", 512, 512, 3, 2, "same")
+    ps = E.ParamStore()
+    layer.declare(ps)
+    ps.materialize(rt)
+    layer.bind(rt, ps)
+    x = _to_nhwc_bf16(rt, torch.randn(2, 512, 4, 4).to(rt.device))
+    y, _, st = layer.forward_stats(x, False)
+    assert st is None and tuple(y.shape) == (2, 2, 2, 512)

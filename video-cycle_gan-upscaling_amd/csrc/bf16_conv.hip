@@ -161,6 +161,8 @@ struct C3Params {
     int n, h, w_, tiles_x, tiles_y, total;
     int act;
     float act_alpha;
+    float* stats;            // v2 with STATS: per-channel sum / sum of squares of the stored (bf16-rounded) output, [unit][row group][2][64]
+    int stats_per_tile;      // 0: unit = workgroup (one record pair per launch: batch statistics); 1: unit = tile (instance norm)
 };
 
 // workgroup barrier ordering LDS only: global stores stay in flight across it
@@ -409,7 +411,13 @@ __device__ unsigned long long vcg_v2_stamp_sums[256 * 4 * 6];
 #define V2_STAMP_ADD(sum, a, b) do { } while (0)
 #endif
 
-template <bool AFF, bool SLOPE>
+// STATS: the epilogue also accumulates, per lane, the sum and the sum of squares of the values it stores (as rounded to bf16: the
+// statistics are those of the tensor the next kernel reads) for the training-mode BatchNormalization / instance norm behind the
+// convolution (model.py:20,23,284) -- the separate statistics pass over the output (one more read of the tensor, two more launches
+// per normalisation) is gone.  16 values of a store unit cost 24 vector instructions in two more stages of the drain; the 32 partial
+// sums of a lane are reduced over the 32 pixels of the wave once per launch (once per tile for per-image statistics) and written as
+// one record per (workgroup | tile, row group); vcg_norm_finalize_partials sums the records in a fixed order.
+template <bool AFF, bool SLOPE, bool STATS = false>
 __global__ __launch_bounds__(V2_NT, 1) void conv3x3_c64_bf16_v2_kernel(C3Params p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 #ifdef VCG_V2_STAMPS
@@ -520,6 +528,10 @@ __global__ __launch_bounds__(V2_NT, 1) void conv3x3_c64_bf16_v2_kernel(C3Params 
     // the unit in seven stages, so that a stage fits the shadow of one MFMA (32 cycles = about seven VALU instructions):
     //   0, 1: accumulator reads + permlane swaps of channels 0-3 / 4-7;  2..5: scale / shift / slope of two values each;  6: pack + store
     float ev[8];
+    float sacc[32];                                              // STATS: [sum | sum of squares][q][j] of this lane's 16 channels
+    unsigned ovb[4];                                             // STATS: the unit's packed output between its store and its two statistics stages
+#pragma unroll
+    for (int i = 0; i < 32; ++i) sacc[i] = 0.f;
     auto epi_stage = [&](f32x16 (&acc)[4], const OutPos& o, int u, int st) {
         const int q = u >> 2, n = u & 3;
         if (st == 0 && n == 0) epi_params(q);
@@ -542,14 +554,42 @@ __global__ __launch_bounds__(V2_NT, 1) void conv3x3_c64_bf16_v2_kernel(C3Params 
                 ev[j] = t;
             }
             asm volatile("" : "+v"(ev[2 * (st - 2)]), "+v"(ev[2 * (st - 2) + 1]));
-        } else {
+        } else if (st == 6) {
             bf16x8 ov;
 #pragma unroll
             for (int j = 0; j < 8; ++j) ov[j] = (__bf16)ev[j];
             // through the image's buffer descriptor: an out-of-image lane (or a half with nothing pending) gets the out-of-range
             // offset instead of an exec mask -- no branch to split the schedule, and hipcc can count the stores in its vmcnt waits
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ov), o.rs, (int)out_off(o, n, q), 0, 0);
+            const u32x4 ob = __builtin_bit_cast(u32x4, ov);
+            __builtin_amdgcn_raw_buffer_store_b128(ob, o.rs, (int)out_off(o, n, q), 0, 0);
+            if (STATS) {
+                // what the statistics stages read: zero for a pixel outside the image (its accumulators hold the bias)
+                const unsigned m = (o.gy0 + n < p.h && o.okx) ? 0xFFFFFFFFu : 0u;
+#pragma unroll
+                for (int d = 0; d < 4; ++d) ovb[d] = ob[d] & m;
+                asm volatile("" : "+v"(ovb[0]), "+v"(ovb[1]), "+v"(ovb[2]), "+v"(ovb[3]));
+            }
+        } else if (STATS) {
+            // stages 7, 8: channels 4(st-7) .. 4(st-7)+3 of the unit, unpacked from the stored bf16 pairs
+#pragma unroll
+            for (int d = 2 * (st - 7); d < 2 * (st - 7) + 2; ++d) {
+                const float lo = __uint_as_float(ovb[d] << 16), hi = __uint_as_float(ovb[d] & 0xFFFF0000u);
+                sacc[8 * q + 2 * d] += lo;
+                sacc[16 + 8 * q + 2 * d] = fmaf(lo, lo, sacc[16 + 8 * q + 2 * d]);
+                sacc[8 * q + 2 * d + 1] += hi;
+                sacc[16 + 8 * q + 2 * d + 1] = fmaf(hi, hi, sacc[16 + 8 * q + 2 * d + 1]);
+            }
+            asm volatile("" : "+v"(sacc[8 * q + 4 * (st - 7)]), "+v"(sacc[8 * q + 4 * (st - 7) + 1]), "+v"(sacc[8 * q + 4 * (st - 7) + 2]),
+                         "+v"(sacc[8 * q + 4 * (st - 7) + 3]), "+v"(sacc[16 + 8 * q + 4 * (st - 7)]), "+v"(sacc[16 + 8 * q + 4 * (st - 7) + 1]),
+                         "+v"(sacc[16 + 8 * q + 4 * (st - 7) + 2]), "+v"(sacc[16 + 8 * q + 4 * (st - 7) + 3]));
         }
+    };
+    // STATS: the lane sums -> one record: lane (r, hh) ends up with value r = [stat][q][j] summed over the wave's 32 pixels
+    auto stats_flush = [&](int unit) {
+        const float t = half_wave_reduce_scatter32(sacc, r);
+        p.stats[(((long)unit * 2 + rg) * 2 + (r >> 4)) * 64 + coh * 32 + ((r >> 3) & 1) * 16 + 8 * hh + (r & 7)] = t;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) sacc[i] = 0.f;
     };
     // one phase: 12 k-groups of 12 MFMAs into `acc` (rows 4h..4h+3), the next group's six rows read under them, `drain`'s eight
     // store units in groups 2..9, and (phase A only) two DMA pieces of the next tile in groups 0..9.  The order inside a group is
@@ -579,6 +619,7 @@ __global__ __launch_bounds__(V2_NT, 1) void conv3x3_c64_bf16_v2_kernel(C3Params 
                 if (i == 3 && dm) dma(np, nbuf, 2 * g + 1);
                 if (dr && i == 2) epi_stage(drain, dpos, g - 2, 0);
                 if (dr && i >= 4 && i <= 9) epi_stage(drain, dpos, g - 2, i - 3);
+                if (STATS && dr && i >= 10) epi_stage(drain, dpos, g - 2, i - 3);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -608,6 +649,7 @@ __global__ __launch_bounds__(V2_NT, 1) void conv3x3_c64_bf16_v2_kernel(C3Params 
         const OutPos p0{yrs, gx, tyi * V2_TR + rg * 8, gx < p.w_}, p1{yrs, gx, tyi * V2_TR + rg * 8 + 4, gx < p.w_};
         frag(xb, 0, 0, 0);
         phase(acc0, acc1, pv, xb, 0, np, buf ^ 1, has_next);      // half 0; drains the previous tile's half 1
+        if (STATS && p.stats_per_tile && tile != (int)blockIdx.x) stats_flush(tile - (int)gridDim.x);     // the previous tile is complete
         V2_STAMP(st1);
         phase(acc1, acc0, p0, xb, 1, np, buf ^ 1, has_next);      // half 1; drains this tile's half 0
         pv = p1;
@@ -628,7 +670,8 @@ __global__ __launch_bounds__(V2_NT, 1) void conv3x3_c64_bf16_v2_kernel(C3Params 
 #pragma unroll
     for (int u = 0; u < 8; ++u)
 #pragma unroll
-        for (int st = 0; st < 7; ++st) epi_stage(acc1, pv, u, st);
+        for (int st = 0; st < (STATS ? 9 : 7); ++st) epi_stage(acc1, pv, u, st);
+    if (STATS) stats_flush(p.stats_per_tile ? tile - (int)gridDim.x : (int)blockIdx.x);
 #ifdef VCG_V2_STAMPS
     if (lane == 0) {
         unsigned long long* o = vcg_v2_stamp_sums + (blockIdx.x * 4 + wv) * 6;
@@ -663,6 +706,7 @@ struct I9Params {
     __bf16* y;               // bf16 NHWC [n][h][w][cout]
     const __bf16* mask;      // optional bf16 NHWC [n][h][w][cout]: y *= (mask > 0 ? 1 : mask_slope)  (data gradient in front of a LeakyReLU)
     float mask_slope;
+    float* chsum;            // optional [workgroups per channel block * 6][cout]: per-wave sums of the stored output per channel (a bias gradient)
     int n, h, w_, cout, tiles_x, tiles_y, total;        // cout = 64 * nblk; workgroup b serves channel block b % nblk
 };
 
@@ -731,6 +775,9 @@ __global__ __launch_bounds__(NT, 1) void conv9x9_c3to64_bf16_kernel(I9Params p) 
 
     const int aoff = r * 32 + hh * 16;                         // weight fragment of (co = r [+32], half)
     const unsigned char* xb = xl + (wv * 2) * I_ROWB + (r + 2 * hh) * 8;
+    float csum[32];                                            // p.chsum: this lane's 32 channels [mt][q][j], summed over its pixels
+#pragma unroll
+    for (int i = 0; i < 32; ++i) csum[i] = 0.f;
     lds_barrier();
 
     for (int tile = wg0; tile < p.total; tile += nwg) {
@@ -806,9 +853,18 @@ __global__ __launch_bounds__(NT, 1) void conv9x9_c3to64_bf16_kernel(I9Params p) 
                         ov[j] = (__bf16)u;
                     }
                     if (ok) *(bf16x8*)(p.y + o) = ov;
+                    if (p.chsum && ok) {                             // the values as stored
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) csum[mt * 16 + q * 8 + j] += (float)ov[j];
+                    }
                 }
             }
         lds_barrier();
+    }
+    if (p.chsum) {
+        // lane (r, hh) ends up with the sum of value r = [mt][q][j] over the wave's 32 pixel lanes: channel mt*32 + 16q + 8hh + j
+        const float t = half_wave_reduce_scatter32(csum, r);
+        p.chsum[(long)(wg0 * NCW + wv) * p.cout + cb * 64 + (r >> 4) * 32 + ((r >> 3) & 1) * 16 + 8 * hh + (r & 7)] = t;
     }
 }
 
@@ -1226,6 +1282,21 @@ int vcg_bf16_nhwc_to_f32_nchw(const void* x, void* y, int32_t n, int32_t c, int3
     return VCG_OK;
 }
 
+// the v2 kernel finds its halo rows through 32-bit byte offsets against the image's buffer descriptor: the image plus the halo rows
+// below it (and a row of slack for the wrapped offsets of the row above it) must stay below 4 GiB, or a halo offset wraps into the image
+static bool v2_image_fits(int h, int w) { return ((long)h + V2_HR + 2) * w * 128 + 4096 <= 0xFFFFFFE0l; }
+
+int vcg_conv2d_bf16_stats_records(const vcg_conv_desc* d, int32_t stats_mode) {
+    if (d == nullptr) return VCG_E_NULL;
+    if (d->n <= 0 || d->h <= 0 || d->w <= 0) return VCG_E_SHAPE;
+    if (stats_mode != VCG_STATS_BATCH && stats_mode != VCG_STATS_INSTANCE) return VCG_E_UNSUPPORTED;
+    if (!(d->cin == 64 && d->cout == 64 && d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad_top == 1 && d->pad_left == 1)) return VCG_E_UNSUPPORTED;
+    if (getenv("VCG_CONV3X3_V1") != nullptr || !v2_image_fits(d->h, d->w)) return VCG_E_UNSUPPORTED;
+    const long tiles_img = (long)ceil_div(d->w, V2_TC) * ceil_div(d->h, V2_TR), total = tiles_img * d->n;
+    if (stats_mode == VCG_STATS_INSTANCE) return (int)(2 * tiles_img);
+    return (int)(2 * (total < 256 ? total : 256));
+}
+
 int vcg_conv2d_bf16_fwd(const vcg_conv_desc* d, const void* x, const void* w_packed, void* y, const vcg_epilogue_bf16* ep,
                         hipStream_t stream) {
     VCG_CHECK_PTR(d);
@@ -1254,6 +1325,13 @@ int vcg_conv2d_bf16_fwd(const vcg_conv_desc* d, const void* x, const void* w_pac
         p.total = p.n * p.tiles_x * p.tiles_y;
         p.act = act;
         p.act_alpha = ep ? ep->act_alpha : 0.f;
+        p.stats = (ep && ep->stats_mode != VCG_STATS_NONE) ? (float*)ep->stats : nullptr;
+        p.stats_per_tile = ep && ep->stats_mode == VCG_STATS_INSTANCE;
+        if (ep && ep->stats_mode != VCG_STATS_NONE) {
+            // statistics come out of the v2 kernel's drain: no activation, no residual input (what stands in front of a normalisation)
+            if (!ep->stats) return VCG_E_NULL;
+            if (vcg_conv2d_bf16_stats_records(d, ep->stats_mode) <= 0 || act != VCG_ACT_NONE || ep->residual) return VCG_E_UNSUPPORTED;
+        }
         static bool attr_set = false;
         if (!attr_set) {
             for (auto f : {(const void*)conv3x3_c64_bf16_kernel<false, false, false>, (const void*)conv3x3_c64_bf16_kernel<false, false, true>,
@@ -1269,14 +1347,15 @@ int vcg_conv2d_bf16_fwd(const vcg_conv_desc* d, const void* x, const void* w_pac
         // v2 (one wave per SIMD, weights in registers) unless there is a residual input or the image is too large for one
         // buffer descriptor; VCG_CONV3X3_V1=1 forces v1 (A/B aid: scripts/gpu_v2_ab.sh)
         static const bool use_v1 = getenv("VCG_CONV3X3_V1") != nullptr;
-        if (!use_v1 && !res && (long)d->h * d->w * 128 <= 0xFFFFFFE0l) {
+        if (!use_v1 && !res && v2_image_fits(d->h, d->w)) {
             p.tiles_x = ceil_div(d->w, V2_TC);
             p.tiles_y = ceil_div(d->h, V2_TR);
             p.total = p.n * p.tiles_x * p.tiles_y;
             static bool attr2_set = false;
             if (!attr2_set) {
                 for (auto f : {(const void*)conv3x3_c64_bf16_v2_kernel<false, false>, (const void*)conv3x3_c64_bf16_v2_kernel<false, true>,
-                               (const void*)conv3x3_c64_bf16_v2_kernel<true, false>, (const void*)conv3x3_c64_bf16_v2_kernel<true, true>}) {
+                               (const void*)conv3x3_c64_bf16_v2_kernel<true, false>, (const void*)conv3x3_c64_bf16_v2_kernel<true, true>,
+                               (const void*)conv3x3_c64_bf16_v2_kernel<true, false, true>}) {
                     hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, V2_LDS);
                     if (e != hipSuccess) return (int)e;
                 }
@@ -1284,7 +1363,9 @@ int vcg_conv2d_bf16_fwd(const vcg_conv_desc* d, const void* x, const void* w_pac
             }
             const int grid2 = p.total < 256 ? p.total : 256;
 #define VCG_C3V2_LAUNCH(A, S) conv3x3_c64_bf16_v2_kernel<A, S><<<grid2, V2_NT, V2_LDS, stream>>>(p)
-            if (aff) {
+            if (p.stats) {
+                conv3x3_c64_bf16_v2_kernel<true, false, true><<<grid2, V2_NT, V2_LDS, stream>>>(p);      // a null scale / shift reads as 1 / 0
+            } else if (aff) {
                 if (slope) VCG_C3V2_LAUNCH(true, true); else VCG_C3V2_LAUNCH(true, false);
             } else {
                 if (slope) VCG_C3V2_LAUNCH(false, true); else VCG_C3V2_LAUNCH(false, false);
@@ -1318,7 +1399,7 @@ int vcg_conv_transpose2d_bf16_fwd(const vcg_conv_desc* d, const void* x, const v
     if (d->n <= 0 || d->h <= 0 || d->w <= 0) return VCG_E_SHAPE;
     if (d->oh != 2 * d->h || d->ow != 2 * d->w || d->stride != 2) return VCG_E_SHAPE;
     const int act = ep ? ep->act : VCG_ACT_NONE;
-    if (ep && (ep->scale || ep->residual)) return VCG_E_UNSUPPORTED;
+    if (ep && (ep->scale || ep->residual || ep->stats_mode != VCG_STATS_NONE)) return VCG_E_UNSUPPORTED;
     if (act != VCG_ACT_NONE && act != VCG_ACT_LRELU) return VCG_E_UNSUPPORTED;
     const int nblk = d->cout / 64;
     if (d->cin != 64 || d->cout % 64 != 0 || (nblk & (nblk - 1)) != 0 || nblk > 8 || d->kh != 3 || d->kw != 3) return VCG_E_UNSUPPORTED;
@@ -1404,11 +1485,19 @@ int vcg_pack_conv9x9_3ch_bf16(const void* w, int32_t cout, int32_t dgrad, void* 
     return VCG_OK;
 }
 
+static int conv9x9_3ch_wgs(const vcg_conv_desc* d, int cout) {          // workgroups per output-channel block
+    const int nblk = cout / 64;
+    const long total = (long)d->n * ceil_div(d->w, TC) * ceil_div(d->h, TR);
+    const int per = 512 / nblk;                                   // 62 KiB of LDS: two workgroups per CU
+    return (int)(per > total ? total : per);
+}
+
 static int launch_conv9x9_3ch(const vcg_conv_desc* d, int cout, const void* x, const void* wfrag, const void* bias, const void* prelu_alpha,
-                              const void* mask, float mask_slope, void* y, hipStream_t stream) {
+                              const void* mask, float mask_slope, void* y, float* chsum, hipStream_t stream) {
     const int nblk = cout / 64;
     if (cout % 64 != 0 || nblk < 1 || nblk > 8 || (nblk & (nblk - 1))) return VCG_E_UNSUPPORTED;
     I9Params p;
+    p.chsum = chsum;
     p.x = (const float*)x;
     p.w = (const uint4*)wfrag;
     p.bias = (const float*)bias;
@@ -1430,8 +1519,7 @@ static int launch_conv9x9_3ch(const vcg_conv_desc* d, int cout, const void* x, c
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    int per = 512 / nblk;                                   // 62 KiB of LDS: two workgroups per CU
-    if (per > p.total) per = p.total;
+    const int per = conv9x9_3ch_wgs(d, cout);
     conv9x9_c3to64_bf16_kernel<<<per * nblk, NT, lds, stream>>>(p);
     VCG_LAUNCH_CHECK();
     return VCG_OK;
@@ -1445,7 +1533,7 @@ int vcg_conv9x9_from3_bf16_fwd(const vcg_conv_desc* d, const void* x, const void
     VCG_CHECK_PTR(y);
     if (d->n <= 0 || d->h <= 0 || d->w <= 0 || d->oh != d->h || d->ow != d->w) return VCG_E_SHAPE;
     if (d->cin != 3 || d->kh != 9 || d->kw != 9 || d->stride != 1 || d->pad_top != 4 || d->pad_left != 4) return VCG_E_UNSUPPORTED;
-    return launch_conv9x9_3ch(d, d->cout, x, wfrag, bias, prelu_alpha, nullptr, 0.f, y, stream);
+    return launch_conv9x9_3ch(d, d->cout, x, wfrag, bias, prelu_alpha, nullptr, 0.f, y, nullptr, stream);
 }
 
 int vcg_conv9x9_to3_bf16_dgrad(const vcg_conv_desc* d, const void* dy, const void* wfrag, const void* y_prev, float lrelu_slope, void* dx,
@@ -1456,7 +1544,28 @@ int vcg_conv9x9_to3_bf16_dgrad(const vcg_conv_desc* d, const void* dy, const voi
     VCG_CHECK_PTR(dx);
     if (d->n <= 0 || d->h <= 0 || d->w <= 0 || d->oh != d->h || d->ow != d->w) return VCG_E_SHAPE;
     if (d->cout != 3 || d->kh != 9 || d->kw != 9 || d->stride != 1 || d->pad_top != 4 || d->pad_left != 4) return VCG_E_UNSUPPORTED;
-    return launch_conv9x9_3ch(d, d->cin, dy, wfrag, nullptr, nullptr, y_prev, lrelu_slope, dx, stream);
+    return launch_conv9x9_3ch(d, d->cin, dy, wfrag, nullptr, nullptr, y_prev, lrelu_slope, dx, nullptr, stream);
+}
+
+// the same, also leaving per-channel sums of the stored dx as records [vcg_conv9x9_to3_bf16_dgrad_chsum_records(d)][cin] -- the bias gradient of
+// the layer that produced the convolution's input (upsampling_block's Conv2DTranspose, model.py:72) without another pass over dx; add the
+// records up with vcg_sum_records
+int vcg_conv9x9_to3_bf16_dgrad_chsum_records(const vcg_conv_desc* d) {
+    if (d == nullptr) return VCG_E_NULL;
+    if (d->n <= 0 || d->h <= 0 || d->w <= 0 || d->cin <= 0 || d->cin % 64) return VCG_E_SHAPE;
+    return conv9x9_3ch_wgs(d, d->cin) * NCW;
+}
+
+int vcg_conv9x9_to3_bf16_dgrad_chsum(const vcg_conv_desc* d, const void* dy, const void* wfrag, const void* y_prev, float lrelu_slope, void* dx,
+                                     float* records, hipStream_t stream) {
+    VCG_CHECK_PTR(d);
+    VCG_CHECK_PTR(dy);
+    VCG_CHECK_PTR(wfrag);
+    VCG_CHECK_PTR(dx);
+    VCG_CHECK_PTR(records);
+    if (d->n <= 0 || d->h <= 0 || d->w <= 0 || d->oh != d->h || d->ow != d->w) return VCG_E_SHAPE;
+    if (d->cout != 3 || d->kh != 9 || d->kw != 9 || d->stride != 1 || d->pad_top != 4 || d->pad_left != 4) return VCG_E_UNSUPPORTED;
+    return launch_conv9x9_3ch(d, d->cin, dy, wfrag, nullptr, nullptr, y_prev, lrelu_slope, dx, records, stream);
 }
 
 }  // extern "C"

@@ -41,6 +41,7 @@ struct GcParams {
     int ntaps, mblocks;
     int act;
     float alpha, mask_slope;
+    float* stats;           // LDS-tiled kernel only: per-tile sums / sums of squares of the stored output, [n][tiles per image][2][mch]
     GcTap taps[GC_MAXTAPS];
 };
 
@@ -199,6 +200,7 @@ struct GlParams {
     float alpha, mask_slope;
     int isy, isx;           // input pixel of plane (py, px), plane coordinates (i, j): (isy*i + py, isx*j + px)
     int tiles_x, tiles_y, pairs, mgroups, nplanes;
+    float* stats;           // optional: [n][tiles_y * tiles_x][2][mch] sums and sums of squares of the stored (bf16-rounded) output per tile
     struct Plane {
         int py, px, dy0, dx0;     // parity; smallest tap offsets in plane coordinates: halo origin of a tile = (ly0 + dy0, lx0 + dx0)
         int wt[25];               // weight tap of offset (dyo, dxo) from the halo origin, row-major (SP+1)^2, or -1  (dwords: scalar loads)
@@ -268,6 +270,10 @@ __global__ __launch_bounds__(256, 1) void gconv_lds_bf16_kernel(const GlParams p
     for (int n = 0; n < GL_TR; ++n)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[n][e] = 0.f;
+    // statistics for the normalisation behind the convolution (p.stats): per lane [sum | sum of squares][q][j] of its 16 channels
+    float sacc[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) sacc[i] = 0.f;
 
     int buf = 0, c = 0;
     while (true) {
@@ -347,8 +353,29 @@ __global__ __launch_bounds__(256, 1) void gconv_lds_bf16_kernel(const GlParams p
                         if (p.mask_src) u *= ((float)mk[j] > 0.f ? 1.f : p.mask_slope);
                         o[j] = (__bf16)u;
                     }
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), ry, (int)off, 0, 0);
+                    const u32x4 ob = __builtin_bit_cast(u32x4, o);
+                    __builtin_amdgcn_raw_buffer_store_b128(ob, ry, (int)off, 0, 0);
+                    if (p.stats) {                                   // (uniform) the values as stored, zero outside the tensor
+                        const unsigned m = ok ? 0xFFFFFFFFu : 0u;
+#pragma unroll
+                        for (int d = 0; d < 4; ++d) {
+                            const unsigned w = ob[d] & m;
+                            const float lo = __uint_as_float(w << 16), hi = __uint_as_float(w & 0xFFFF0000u);
+                            sacc[8 * q + 2 * d] += lo;
+                            sacc[16 + 8 * q + 2 * d] = fmaf(lo, lo, sacc[16 + 8 * q + 2 * d]);
+                            sacc[8 * q + 2 * d + 1] += hi;
+                            sacc[16 + 8 * q + 2 * d + 1] = fmaf(hi, hi, sacc[16 + 8 * q + 2 * d + 1]);
+                        }
+                    }
                 }
+            }
+            if (p.stats) {
+                // one record per tile: lane (r, hh) ends up with value r = [stat][q][j] summed over the tile's 8 x 32 pixels
+                const float t = half_wave_reduce_scatter32(sacc, r);
+                const long tile = ((long)cur.img * p.tiles_y + cur.ty) * p.tiles_x + cur.tx;
+                if (mtile < p.mblocks) p.stats[(tile * 2 + (r >> 4)) * p.mch + mtile * 32 + ((r >> 3) & 1) * 16 + 8 * hh + (r & 7)] = t;
+#pragma unroll
+                for (int i = 0; i < 32; ++i) sacc[i] = 0.f;
             }
 #pragma unroll
             for (int n = 0; n < GL_TR; ++n)
@@ -409,11 +436,11 @@ int launch_gconv_lds_sp(const GlParams& q, int grid, hipStream_t st) {
 
 // the LDS-tiled kernel where it applies (input stride 1 or 2, 64-channel input chunks, >= 64 output channels, the taps of a parity plane
 // inside a 5x5 box, images below 4 GiB, enough tiles to fill the chip); VCG_GCONV_LDS=0 forces the streaming kernel (A/B aid)
-bool try_gconv_lds(const GcParams& p, hipStream_t st, int* rc) {
+bool plan_gconv_lds(const GcParams& p, GlParams& q, int& spe_out) {
     static const bool off = getenv("VCG_GCONV_LDS") && atoi(getenv("VCG_GCONV_LDS")) == 0;
     if (off || p.isy != p.isx || p.isy < 1 || p.isy > 2 || p.kch % 64 || p.mblocks < 2 || p.ntaps < 1) return false;
     if ((long)p.ih * p.iw * p.kch * 2 > 0xFFFFFFE0l || (long)p.oh * p.ow * p.mch * 2 > 0xFFFFFFE0l) return false;
-    GlParams q{};
+    q = GlParams{};
     // taps by the parity plane of the input they read: dy = isy * a + py
     const int S = p.isy;
     int sp = 0;
@@ -448,11 +475,19 @@ bool try_gconv_lds(const GcParams& p, hipStream_t st, int* rc) {
     q.x = p.x; q.wf = p.wf; q.y = p.y; q.bias = p.bias; q.mask_src = p.mask_src; q.wbytes = p.wbytes;
     q.n = p.n; q.ih = p.ih; q.iw = p.iw; q.kch = p.kch; q.oh = p.oh; q.ow = p.ow; q.mch = p.mch; q.loh = p.loh; q.low = p.low;
     q.osy = p.osy; q.osx = p.osx; q.ooy = p.ooy; q.oox = p.oox; q.mblocks = p.mblocks; q.act = p.act; q.alpha = p.alpha; q.mask_slope = p.mask_slope;
-    q.isy = p.isy; q.isx = p.isx;
+    q.isy = p.isy; q.isx = p.isx; q.stats = p.stats;
     q.tiles_x = ceil_div(p.low, GL_TC); q.tiles_y = ceil_div(p.loh, GL_TR); q.mgroups = (p.mblocks + 3) / 4;
     const long pairs = (long)p.n * q.tiles_x * q.tiles_y * q.mgroups;
     if (pairs < 64 || pairs > 0x7fffffffL) return false;        // too little work for 256 one-workgroup CUs: the streaming kernel's small tiles fill the chip better
     q.pairs = (int)pairs;
+    spe_out = spe;
+    return true;
+}
+
+bool try_gconv_lds(const GcParams& p, hipStream_t st, int* rc) {
+    GlParams q;
+    int spe = 1;
+    if (!plan_gconv_lds(p, q, spe)) return false;
     const int grid = q.pairs < 256 ? q.pairs : 256;
     switch (spe) {
         case 1: *rc = launch_gconv_lds_sp<1>(q, grid, st); break;
@@ -468,6 +503,7 @@ int launch_gconv(GcParams& p, hipStream_t st) {
     if (total <= 0) return VCG_OK;
     int lrc = VCG_OK;
     if (try_gconv_lds(p, st, &lrc)) return lrc;
+    if (p.stats) return VCG_E_UNSUPPORTED;                       // only the LDS-tiled kernel's epilogue writes statistics
     const long tiles = (total + 31) / 32;
     // 4 tiles per wave (128 accumulator registers, half the operand loads per MFMA) once there is enough work to fill the chip
     const int mgroups = (p.mblocks + 1) / 2;
@@ -523,6 +559,50 @@ int vcg_f32_to_bf16(const float* x, void* y, size_t count, hipStream_t stream) {
     hipLaunchKernelGGL(f32_to_bf16_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, stream, x, (__bf16*)y, count);
     VCG_LAUNCH_CHECK();
     return VCG_OK;
+}
+
+static void fwd_params(const vcg_conv_desc* d, GcParams& p) {
+    p.wbytes = vcg_conv_frag_bf16_bytes(d->kh * d->kw, d->cout, d->cin);
+    p.n = d->n; p.ih = d->h; p.iw = d->w; p.kch = d->cin;
+    p.oh = d->oh; p.ow = d->ow; p.mch = d->cout;
+    p.loh = d->oh; p.low = d->ow; p.osy = p.osx = 1; p.ooy = p.oox = 0;
+    p.isy = p.isx = d->stride;
+    p.mblocks = d->cout / 32;
+    p.ntaps = 0;
+    for (int ky = 0; ky < d->kh; ++ky)
+        for (int kx = 0; kx < d->kw; ++kx) p.taps[p.ntaps++] = GcTap{(short)(ky - d->pad_top), (short)(kx - d->pad_left), (short)(ky * d->kw + kx), 0};
+}
+
+// records per group (image, or the whole batch) that vcg_conv2d_nhwc_bf16_fwd_stats writes for this layer: one per 8 x 32-pixel output
+// tile of the LDS-tiled kernel; a negative VCG_E_* when that kernel does not serve the shape (run vcg_norm_stats_bf16 on the output)
+int vcg_conv2d_nhwc_bf16_stats_records(const vcg_conv_desc* d, int stats_mode) {
+    int rc = check_gdesc(d);
+    if (rc) return rc;
+    if (d->cout % 32 || (stats_mode != VCG_STATS_BATCH && stats_mode != VCG_STATS_INSTANCE)) return VCG_E_UNSUPPORTED;
+    GcParams p{};
+    fwd_params(d, p);
+    GlParams q;
+    int spe = 1;
+    if (!plan_gconv_lds(p, q, spe)) return VCG_E_UNSUPPORTED;
+    const long per_img = (long)q.tiles_x * q.tiles_y, all = per_img * d->n;
+    if (all > 0x3fffffffL) return VCG_E_UNSUPPORTED;
+    return (int)(stats_mode == VCG_STATS_INSTANCE ? per_img : all);
+}
+
+// vcg_conv2d_nhwc_bf16_fwd (no activation) that also leaves, per output tile, the per-channel sum and sum of squares of the values it
+// stored: stats fp32 [n][tiles per image][2][cout] -- read by vcg_norm_finalize_partials as [1][n * tiles][2][cout] (batch statistics) or
+// [n][tiles][2][cout] (instance norm).  The statistics pass of the normalisation behind the layer (model.py:840, the PatchGAN blocks) is gone.
+int vcg_conv2d_nhwc_bf16_fwd_stats(const vcg_conv_desc* d, const void* x, const void* wfrag, const float* bias, void* y, float* stats,
+                                   hipStream_t stream) {
+    int rc = check_gdesc(d);
+    if (rc) return rc;
+    VCG_CHECK_PTR(x); VCG_CHECK_PTR(wfrag); VCG_CHECK_PTR(y); VCG_CHECK_PTR(stats);
+    if (d->cout % 32) return VCG_E_UNSUPPORTED;
+    GcParams p{};
+    p.x = x; p.wf = wfrag; p.y = y; p.bias = bias; p.stats = stats;
+    fwd_params(d, p);
+    p.act = VCG_ACT_NONE;
+    return launch_gconv(p, stream);
 }
 
 // y[n][oh][ow][cout] = act(conv(x) + bias): d describes the Keras layer (pads = TF-SAME "before" pads or explicit padding)

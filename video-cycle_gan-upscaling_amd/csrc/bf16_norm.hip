@@ -30,7 +30,22 @@ __global__ __launch_bounds__(256) void stats_partial_bf16_kernel(const bf16x8* _
     if (pl < npl)
         for (int slab = blk; slab < slabs_per_group; slab += bpg) {
             const long p0 = (long)slab * SPB, p1 = p0 + SPB < group_pixels ? p0 + SPB : group_pixels;
-            for (long p = p0 + pl; p < p1; p += npl) {
+            // four pixels per trip, their loads issued together (one load in flight per thread left the pass latency-bound: 2.3 TB/s)
+            long p = p0 + pl;
+            for (; p + 3 * npl < p1; p += 4 * npl) {
+                bf16x8 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = xg[(p + u * npl) * c8 + ch];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float d = (float)v[u][j] - (float)k8[j];
+                        s[j] += d;
+                        q[j] += d * d;
+                    }
+            }
+            for (; p < p1; p += npl) {
                 const bf16x8 v = xg[p * c8 + ch];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
@@ -116,11 +131,7 @@ __global__ __launch_bounds__(256) void norm_act_fwd_bf16_kernel(const bf16x8* __
     }
     const long p0 = (long)pb * APB, p1 = p0 + APB < pix_per_img ? p0 + APB : pix_per_img;
     const long base = (long)img * pix_per_img * c8;
-    for (long p = p0 + pl; p < p1; p += npl) {
-        const long i = base + p * c8 + ch;
-        const bf16x8 v = x[i];
-        bf16x8 r8;
-        if (res) r8 = res[i];
+    auto one = [&](const bf16x8& v, const bf16x8& r8) {
         bf16x8 o;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -129,7 +140,27 @@ __global__ __launch_bounds__(256) void norm_act_fwd_bf16_kernel(const bf16x8* __
             if (res) u += (float)r8[j];
             o[j] = (__bf16)u;
         }
-        y[i] = o;
+        return o;
+    };
+    // four pixels per trip: all their loads first, then the arithmetic and the stores
+    long p = p0 + pl;
+    for (; p + 3 * npl < p1; p += 4 * npl) {
+        bf16x8 v[4], r8[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long i = base + (p + u * npl) * c8 + ch;
+            v[u] = x[i];
+            if (res) r8[u] = res[i];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) y[base + (p + u * npl) * c8 + ch] = one(v[u], r8[u]);
+    }
+    for (; p < p1; p += npl) {
+        const long i = base + p * c8 + ch;
+        const bf16x8 v = x[i];
+        bf16x8 r8;
+        if (res) r8 = res[i];
+        y[i] = one(v, r8);
     }
 }
 
@@ -166,8 +197,7 @@ __global__ __launch_bounds__(256) void norm_bwd_partial_bf16_kernel(const bf16x8
     if (pl < npl)
         for (int slab = blk; slab < slabs_per_group; slab += bpg) {
             const long p0 = (long)slab * SPB, p1 = p0 + SPB < group_pixels ? p0 + SPB : group_pixels;
-            for (long p = p0 + pl; p < p1; p += npl) {
-                const bf16x8 xv = x[gbase + p * c8 + ch], dv = dy[gbase + p * c8 + ch];
+            auto one = [&](const bf16x8& xv, const bf16x8& dv) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const float xh = ((float)xv[j] - mu[j]) * is[j], u = xh * ga[j] + be[j], d = (float)dv[j];
@@ -176,7 +206,20 @@ __global__ __launch_bounds__(256) void norm_bwd_partial_bf16_kernel(const bf16x8
                     s2[j] += dz * xh;
                     s3[j] += d * fminf(u, 0.f);
                 }
+            };
+            // four pixels per trip, their eight loads issued together (one pair in flight per thread: 2.4 TB/s)
+            long p = p0 + pl;
+            for (; p + 3 * npl < p1; p += 4 * npl) {
+                bf16x8 xv[4], dv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    xv[u] = x[gbase + (p + u * npl) * c8 + ch];
+                    dv[u] = dy[gbase + (p + u * npl) * c8 + ch];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) one(xv[u], dv[u]);
             }
+            for (; p < p1; p += npl) one(x[gbase + p * c8 + ch], dy[gbase + p * c8 + ch]);
         }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -281,9 +324,7 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_bf16_kernel(const bf16x8* 
     }
     const long p0 = (long)pb * APB, p1 = p0 + APB < pix_per_img ? p0 + APB : pix_per_img;
     const long base = (long)img * pix_per_img * c8;
-    for (long p = p0 + pl; p < p1; p += npl) {
-        const long i = base + p * c8 + ch;
-        const bf16x8 xv = x[i], dv = dy[i];
+    auto one = [&](const bf16x8& xv, const bf16x8& dv) {
         bf16x8 o;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -291,7 +332,23 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_bf16_kernel(const bf16x8* 
             const float dz = (float)dv[j] * (u > 0.f ? 1.f : sl[j]) - m1[j] - xh * m2[j];
             o[j] = (__bf16)(ga[j] * is[j] * dz);
         }
-        dx[i] = o;
+        return o;
+    };
+    long p = p0 + pl;
+    for (; p + 3 * npl < p1; p += 4 * npl) {          // four pixels per trip: eight loads in flight per thread
+        bf16x8 xv[4], dv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long i = base + (p + u * npl) * c8 + ch;
+            xv[u] = x[i];
+            dv[u] = dy[i];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) dx[base + (p + u * npl) * c8 + ch] = one(xv[u], dv[u]);
+    }
+    for (; p < p1; p += npl) {
+        const long i = base + p * c8 + ch;
+        dx[i] = one(x[i], dy[i]);
     }
 }
 

@@ -142,6 +142,95 @@ __global__ void finalize_kernel(const float* mean, const float* var, const float
     }
 }
 
+// out[ch] = scale * sum over records of part[rec][ch], in double and in a fixed order (block = 64 channels x 16 record lanes)
+__global__ __launch_bounds__(1024) void sum_records_kernel(const float* __restrict__ part, int nrec, int c, float scale, float* __restrict__ out) {
+    __shared__ double rs[16][64];
+    const int ch = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
+    double s = 0.0;
+    if (ch < c) {
+        int b = g;
+        for (; b + 16 * 7 < nrec; b += 16 * 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = part[(size_t)(b + 16 * u) * c + ch];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; b < nrec; b += 16) s += part[(size_t)b * c + ch];
+    }
+    rs[g][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (g != 0 || ch >= c) return;
+#pragma unroll
+    for (int i = 1; i < 16; ++i) s += rs[i][threadIdx.x];
+    out[ch] = (float)(s * (double)scale);
+}
+
+// inference-mode BatchNormalization behind a convolution as the convolution's epilogue: scale = gamma * rsqrt(moving_var + eps),
+// shift = (bias - moving_mean) * scale + beta  (model.py:19-20 in learning phase 0)
+__global__ void bn_fold_kernel(const float* bias, const float* mmean, const float* mvar, const float* gamma, const float* beta, int c, float eps,
+                               float* scale, float* shift) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= c) return;
+    const float sc = (gamma ? gamma[i] : 1.f) * rsqrtf(mvar[i] + eps);
+    scale[i] = sc;
+    shift[i] = ((bias ? bias[i] : 0.f) - mmean[i]) * sc + (beta ? beta[i] : 0.f);
+}
+
+// mean / biased variance from the partial records a convolution's epilogue wrote (part[group][nrec][2][c]: sums, sums of squares of the
+// stored values), then what finalize_kernel does -- one launch instead of statistics partial + final + finalize.
+// block = (group, 64 channels) x 16 record lanes; a thread sums its records (eight in flight) in double, the 16 lanes combine in a
+// fixed order.  E[x^2] - E[x]^2 is formed in double from fp32 partial sums of <= a few thousand values each: its relative error is
+// ~1e-7 (1 + mean^2/var), fine for the layers behind a convolution (|mean| of the order of the standard deviation).
+__global__ __launch_bounds__(1024) void finalize_partials_kernel(const float* __restrict__ part, int nrec, int c, double inv_count,
+                                                                  const float* gamma, const float* beta, float eps, float* mean_out,
+                                                                  float* scale, float* shift, float* invstd, float* mmean, float* mvar,
+                                                                  float momentum, int unbiased_count, int groups) {
+    __shared__ double rs[16][64], rq[16][64];
+    const int cblocks = (c + 63) / 64, grp = blockIdx.x / cblocks, ch = (blockIdx.x - grp * cblocks) * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
+    double s = 0.0, q = 0.0;
+    if (ch < c) {
+        const float* pg = part + (size_t)grp * nrec * 2 * c + ch;
+        int b = g;
+        for (; b + 16 * 7 < nrec; b += 16 * 8) {
+            float vs[8], vq[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                vs[u] = pg[(size_t)(b + 16 * u) * 2 * c];
+                vq[u] = pg[((size_t)(b + 16 * u) * 2 + 1) * c];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { s += vs[u]; q += vq[u]; }
+        }
+        for (; b < nrec; b += 16) {
+            s += pg[(size_t)b * 2 * c];
+            q += pg[((size_t)b * 2 + 1) * c];
+        }
+    }
+    rs[g][threadIdx.x & 63] = s;
+    rq[g][threadIdx.x & 63] = q;
+    __syncthreads();
+    if (g != 0 || ch >= c) return;
+#pragma unroll
+    for (int i = 1; i < 16; ++i) { s += rs[i][threadIdx.x]; q += rq[i][threadIdx.x]; }
+    const double m = s * inv_count, vd = q * inv_count - m * m;
+    const int i = grp * c + ch;
+    const float mean = (float)m, var = vd > 0.0 ? (float)vd : 0.f;
+    const float is = rsqrtf(var + eps);
+    const float ga = gamma ? gamma[ch] : 1.f, bt = beta ? beta[ch] : 0.f;
+    const float sc = ga * is;
+    mean_out[i] = mean;
+    scale[i] = sc;
+    shift[i] = bt - mean * sc;
+    if (invstd) invstd[i] = is;
+    if (mmean && groups == 1) {
+        mmean[i] = mmean[i] * momentum + mean * (1.f - momentum);
+        float v = var;
+        if (unbiased_count > 1) v *= (float)unbiased_count / (float)(unbiased_count - 1);
+        mvar[i] = mvar[i] * momentum + v * (1.f - momentum);
+    }
+}
+
 // ---- y = act(x*scale + shift) + residual -----------------------------------------------------------
 template <bool VEC>
 __global__ __launch_bounds__(256) void norm_act_fwd_kernel(const float* x, int n, int c, int hw,
@@ -346,6 +435,36 @@ int vcg_norm_finalize(const float* mean, const float* var, const float* gamma, c
     hipLaunchKernelGGL(finalize_kernel, dim3(ceil_div(c * rows, 256)), dim3(256), 0, (hipStream_t)stream, mean, var,
                        gamma, beta, c, rows, eps, scale, shift, invstd, moving_mean, moving_var, momentum,
                        unbiased_count);
+    VCG_LAUNCH_CHECK();
+    return VCG_OK;
+}
+
+int vcg_sum_records(const float* part, int nrec, int c, float scale, float* out, vcg_stream_t stream) {
+    VCG_CHECK_PTR(part); VCG_CHECK_PTR(out);
+    if (nrec <= 0 || c <= 0) return VCG_E_SHAPE;
+    hipLaunchKernelGGL(sum_records_kernel, dim3(ceil_div(c, 64)), dim3(1024), 0, (hipStream_t)stream, part, nrec, c, scale, out);
+    VCG_LAUNCH_CHECK();
+    return VCG_OK;
+}
+
+int vcg_bn_fold(const float* bias, const float* moving_mean, const float* moving_var, const float* gamma, const float* beta, int c, float eps,
+                float* scale, float* shift, vcg_stream_t stream) {
+    VCG_CHECK_PTR(moving_mean); VCG_CHECK_PTR(moving_var); VCG_CHECK_PTR(scale); VCG_CHECK_PTR(shift);
+    if (c <= 0) return VCG_E_SHAPE;
+    hipLaunchKernelGGL(bn_fold_kernel, dim3(ceil_div(c, 256)), dim3(256), 0, (hipStream_t)stream, bias, moving_mean, moving_var, gamma, beta, c, eps,
+                       scale, shift);
+    VCG_LAUNCH_CHECK();
+    return VCG_OK;
+}
+
+int vcg_norm_finalize_partials(const float* part, int nrec, int groups, int c, double count, const float* gamma, const float* beta,
+                               float eps, float* mean, float* scale, float* shift, float* invstd, float* moving_mean,
+                               float* moving_var, float momentum, int unbiased_count, vcg_stream_t stream) {
+    VCG_CHECK_PTR(part); VCG_CHECK_PTR(mean); VCG_CHECK_PTR(scale); VCG_CHECK_PTR(shift);
+    if (c <= 0 || groups <= 0 || nrec <= 0 || !(count > 0.0)) return VCG_E_SHAPE;
+    if ((moving_mean == nullptr) != (moving_var == nullptr)) return VCG_E_NULL;
+    hipLaunchKernelGGL(finalize_partials_kernel, dim3(groups * ceil_div(c, 64)), dim3(1024), 0, (hipStream_t)stream, part, nrec, c,
+                       1.0 / count, gamma, beta, eps, mean, scale, shift, invstd, moving_mean, moving_var, momentum, unbiased_count, groups);
     VCG_LAUNCH_CHECK();
     return VCG_OK;
 }

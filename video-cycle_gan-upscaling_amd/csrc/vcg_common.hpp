@@ -61,6 +61,26 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// reduce-scatter over the 32 lanes of a half-wave: every lane holds 32 values; on return lane r (= lane & 31) holds the sum of
+// value r over those 32 lanes.  Five butterfly steps, the live set halves at each: 31 shuffles instead of 160; the order of the
+// additions is fixed, so the result is deterministic.  (Both half-waves run it at once on their own 32 values.)
+template <int CNT>
+__device__ __forceinline__ void vcg_rs_step(float (&v)[32], bool up, int m) {
+#pragma unroll
+    for (int i = 0; i < CNT; ++i) {
+        const float send = up ? v[i] : v[i + CNT], keep = up ? v[i + CNT] : v[i];
+        v[i] = keep + __shfl_xor(send, m, 64);
+    }
+}
+__device__ __forceinline__ float half_wave_reduce_scatter32(float (&v)[32], int r) {
+    vcg_rs_step<16>(v, (r & 16) != 0, 16);
+    vcg_rs_step<8>(v, (r & 8) != 0, 8);
+    vcg_rs_step<4>(v, (r & 4) != 0, 4);
+    vcg_rs_step<2>(v, (r & 2) != 0, 2);
+    vcg_rs_step<1>(v, (r & 1) != 0, 1);
+    return v[0];
+}
+
 // block-wide sum of up to 3 values, blockDim.x == 256; result valid in thread 0
 template <int NV>
 __device__ __forceinline__ void block_sum(float (&v)[NV], float* smem /* >= 4*NV floats */) {

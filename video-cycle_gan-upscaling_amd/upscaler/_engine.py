@@ -16,6 +16,13 @@ import torch
 
 from . import _lib as L
 
+import os
+
+# VCG_FUSED_STATS=0: the normalisations' statistics by their own pass over the tensor instead of the producing convolution's epilogue (A/B aid)
+FUSED_STATS = os.environ.get("VCG_FUSED_STATS", "1") != "0"
+# VCG_FOLD_PREDICT=0: learning-phase-0 passes of the bf16 trunk as conv -> separate normalisation pass (A/B aid)
+FOLD_PREDICT = os.environ.get("VCG_FOLD_PREDICT", "1") != "0"
+
 BN_EPS = 1e-3          # keras BatchNormalization defaults
 BN_MOMENTUM = 0.99
 IN_EPS = 1e-5          # instance norm (canonical CycleGAN value; no reference counterpart)
@@ -631,12 +638,12 @@ class Conv3x3Bf16(Layer):
             self._valid = True
         return self._wf, self._wd
 
-    def _run(self, x, w, bias, residual=None):
+    def _run(self, x, w, bias, residual=None, stats=None, stats_mode=L.STATS_NONE):
         rt = self.rt
         n, h, wd, _ = x.shape
         y = torch.empty(n, h, wd, 64, dtype=torch.bfloat16, device=rt.device)
         d = L.ConvDesc(n, 64, h, wd, 64, h, wd, 3, 3, 1, 1, 1)
-        ep = L.EpilogueBf16(None, bias, L.ACT_NONE, 0.0, None, _ptr(residual))
+        ep = L.EpilogueBf16(None, bias, L.ACT_NONE, 0.0, None, _ptr(residual), _ptr(stats), stats_mode if stats is not None else L.STATS_NONE)
         L.check(rt.lib.vcg_conv2d_bf16_fwd(ctypes.byref(d), x.data_ptr(), w.data_ptr(), y.data_ptr(), ctypes.byref(ep), rt.stream),
                 "vcg_conv2d_bf16_fwd[%s]" % self.name)
         return y, d
@@ -646,6 +653,43 @@ class Conv3x3Bf16(Layer):
         with Timed(self.rt, tag):
             y, d = self._run(x, wf, self.ps[self.name + "/bias"].data_ptr())
         return y, (x, d)
+
+    def forward_folded(self, x, norm, residual=None, tag=None):
+        """learning phase 0: conv + BatchNormalization (moving statistics) [+ PReLU] [+ Add] in ONE launch -- the normalisation is an
+        affine map per channel, folded with the bias into the epilogue's scale / shift (vcg_bn_fold); the pre-normalisation tensor is
+        never stored.  norm: the NormActBf16 behind this convolution (batch norm)."""
+        rt, ps = self.rt, self.ps
+        n, h, wd, _ = x.shape
+        scale, shift = rt.empty(64), rt.empty(64)
+        L.check(rt.lib.vcg_bn_fold(ps[self.name + "/bias"].data_ptr(), ps[norm.name + "/moving_mean"].data_ptr(),
+                                   ps[norm.name + "/moving_variance"].data_ptr(), ps[norm.name + "/gamma"].data_ptr(),
+                                   ps[norm.name + "/beta"].data_ptr(), 64, BN_EPS, scale.data_ptr(), shift.data_ptr(), rt.stream), "vcg_bn_fold")
+        wf, _ = self._packed()
+        y = torch.empty(n, h, wd, 64, dtype=torch.bfloat16, device=rt.device)
+        d = L.ConvDesc(n, 64, h, wd, 64, h, wd, 3, 3, 1, 1, 1)
+        ep = L.EpilogueBf16(scale.data_ptr(), shift.data_ptr(), norm.act, float(norm.alpha), norm._alpha_ptr(), _ptr(residual), None, L.STATS_NONE)
+        with Timed(rt, tag):
+            L.check(rt.lib.vcg_conv2d_bf16_fwd(ctypes.byref(d), x.data_ptr(), wf.data_ptr(), y.data_ptr(), ctypes.byref(ep), rt.stream),
+                    "vcg_conv2d_bf16_fwd[%s]" % self.name)
+        return y
+
+    def forward_stats(self, x, instance, tag=None):
+        """forward that also leaves the statistics partials of its output for the normalisation behind it (model.py:20,23,284 in
+        training mode): returns (y, ctx, stats) with stats = (records buffer, records per group) or None when the kernel serving
+        this shape has no statistics epilogue (the caller then runs the separate statistics pass)"""
+        rt = self.rt
+        n, h, wd, _ = x.shape
+        mode = L.STATS_INSTANCE if instance else L.STATS_BATCH
+        d = L.ConvDesc(n, 64, h, wd, 64, h, wd, 3, 3, 1, 1, 1)
+        nrec = rt.lib.vcg_conv2d_bf16_stats_records(ctypes.byref(d), mode) if FUSED_STATS else -1
+        if nrec <= 0:
+            y, ctx = self.forward(x, tag)
+            return y, ctx, None
+        buf = rt.empty((n if instance else 1) * nrec * 2 * 64)
+        wf, _ = self._packed()
+        with Timed(rt, tag):
+            y, d = self._run(x, wf, self.ps[self.name + "/bias"].data_ptr(), None, buf, mode)
+        return y, (x, d), (buf, nrec)
 
     def backward(self, ctx, dy, need_dx=True, param_grads=True, which=0, dx_residual=None, tag=None):
         """dx_residual: a gradient that joins at this layer's input (the block's skip branch), added in the epilogue"""
@@ -707,6 +751,24 @@ class Conv2DBf16(Conv2D):
             L.check(rt.lib.vcg_conv2d_nhwc_bf16_fwd(ctypes.byref(d), x.data_ptr(), wf.data_ptr(), self.ps[self.name + "/bias"].data_ptr(),
                                                     L.ACT_NONE, 0.0, y.data_ptr(), rt.stream), "vcg_conv2d_nhwc_bf16_fwd[%s]" % self.name)
         return y, (x, None, d)
+
+    def forward_stats(self, x, instance, tag=None):
+        """forward + per-tile statistics partials of the output (see Conv3x3Bf16.forward_stats)"""
+        rt = self.rt
+        n, h, w, _ = x.shape
+        d = self.desc(n, h, w)
+        mode = L.STATS_INSTANCE if instance else L.STATS_BATCH
+        nrec = rt.lib.vcg_conv2d_nhwc_bf16_stats_records(ctypes.byref(d), mode) if FUSED_STATS else -1
+        if nrec <= 0:
+            y, ctx = self.forward(x, tag=tag)
+            return y, ctx, None
+        wf, _ = self._packed()
+        y = torch.empty(n, d.oh, d.ow, self.cout, dtype=torch.bfloat16, device=rt.device)
+        buf = rt.empty((n if instance else 1) * nrec * 2 * self.cout)
+        with Timed(rt, tag):
+            L.check(rt.lib.vcg_conv2d_nhwc_bf16_fwd_stats(ctypes.byref(d), x.data_ptr(), wf.data_ptr(), self.ps[self.name + "/bias"].data_ptr(),
+                                                          y.data_ptr(), buf.data_ptr(), rt.stream), "vcg_conv2d_nhwc_bf16_fwd_stats[%s]" % self.name)
+        return y, (x, None, d), (buf, nrec)
 
     def backward(self, ctx, dy, need_dx=True, param_grads=True, which=0, dx_residual=None, tag=None):
         rt = self.rt
@@ -784,8 +846,9 @@ class ConvT3x3Bf16(ConvT2D):
                     "vcg_conv_transpose2d_bf16_fwd[%s]" % self.name)
         return y, (x, y, d)
 
-    def backward(self, ctx, dz, need_dx=True, param_grads=True, which=0, tag=None):
-        """dz: bf16 NHWC gradient in front of the LeakyReLU.  Returns dx as bf16 NHWC."""
+    def backward(self, ctx, dz, need_dx=True, param_grads=True, which=0, tag=None, dz_channel_sums=None):
+        """dz: bf16 NHWC gradient in front of the LeakyReLU.  Returns dx as bf16 NHWC.  dz_channel_sums: (records, count) left by the
+        kernel that produced dz (FinalConv9x9Bf16.backward) -- the bias gradient then needs no pass over dz."""
         rt, lib = self.rt, self.rt.lib
         x, _, d = ctx
         _, wg = self._packed()
@@ -795,7 +858,13 @@ class ConvT3x3Bf16(ConvT2D):
                 L.check(lib.vcg_conv_transpose2d_nhwc_bf16_wgrad(ctypes.byref(d), x.data_ptr(), dz.data_ptr(),
                                                                  self.ps.grad(self.name + "/kernel", which).data_ptr(), ws, wsn, rt.stream),
                         "vcg_conv_transpose2d_nhwc_bf16_wgrad[%s]" % self.name)
-            # bias gradient: sum of dz over (n, h, w) = its per-channel mean x count
+            # bias gradient: sum of dz over (n, h, w)
+            if dz_channel_sums is not None:
+                rec, nrec = dz_channel_sums
+                L.check(lib.vcg_sum_records(rec.data_ptr(), nrec, self.cout, 1.0, self.ps.grad(self.name + "/bias", which).data_ptr(), rt.stream),
+                        "vcg_sum_records[%s]" % self.name)
+        if param_grads and dz_channel_sums is None:
+            # ... = its per-channel mean x count (the shifted sums of vcg_norm_stats_bf16)
             hw = d.oh * d.ow
             mean, var = rt.empty(self.cout), rt.empty(self.cout)
             ws, wsn = rt.workspace(lib.vcg_norm_stats_bf16_workspace_bytes(d.n, self.cout, hw, L.NORM_BATCH))
@@ -853,8 +922,10 @@ class FinalConv9x9Bf16(Conv2D):
                                                     1 if self.act == L.ACT_TANH else 0, y.data_ptr(), rt.stream), "vcg_conv9x9_to3_bf16_fwd")
         return y, (x, y, d)
 
-    def backward(self, ctx, dy, need_dx=True, param_grads=True, which=0, tag=None, input_lrelu_slope=None):
-        """returns dx as bf16 NHWC; with input_lrelu_slope it is already the gradient in front of the LeakyReLU whose output x is"""
+    def backward(self, ctx, dy, need_dx=True, param_grads=True, which=0, tag=None, input_lrelu_slope=None, want_channel_sums=False):
+        """returns dx as bf16 NHWC; with input_lrelu_slope it is already the gradient in front of the LeakyReLU whose output x is.
+        want_channel_sums: returns (dx, (records, count)) -- per-channel sums of dx out of the kernel's epilogue (the producing layer's
+        bias gradient, ConvT3x3Bf16.backward)"""
         rt = self.rt
         x, y, d = ctx
         n = d.n
@@ -889,6 +960,16 @@ class FinalConv9x9Bf16(Conv2D):
             return None
         _, wd = self._packed()
         dx = torch.empty_like(x)
+        if want_channel_sums:
+            nrec = rt.lib.vcg_conv9x9_to3_bf16_dgrad_chsum_records(ctypes.byref(d))
+            L.check(min(nrec, 0), "vcg_conv9x9_to3_bf16_dgrad_chsum_records")
+            rec = rt.empty(nrec * self.cin)
+            with Timed(rt, tag and tag + "_dgrad"):
+                L.check(rt.lib.vcg_conv9x9_to3_bf16_dgrad_chsum(ctypes.byref(d), dy.data_ptr(), wd.data_ptr(),
+                                                                x.data_ptr() if input_lrelu_slope is not None else None,
+                                                                float(input_lrelu_slope or 0.0), dx.data_ptr(), rec.data_ptr(), rt.stream),
+                        "vcg_conv9x9_to3_bf16_dgrad_chsum")
+            return dx, (rec, nrec)
         with Timed(rt, tag and tag + "_dgrad"):
             L.check(rt.lib.vcg_conv9x9_to3_bf16_dgrad(ctypes.byref(d), dy.data_ptr(), wd.data_ptr(),
                                                       x.data_ptr() if input_lrelu_slope is not None else None,
@@ -909,7 +990,13 @@ class NormActBf16(Layer):
     init_weights = NormAct.init_weights
     _alpha_ptr = NormAct._alpha_ptr
 
-    def forward(self, x, training, residual=None, update_moving=True):
+    def needs_stats(self, training):
+        """does forward(x, training) compute statistics of x (so that a producer's epilogue may hand them over)"""
+        return bool(training or self.norm == "instance")
+
+    def forward(self, x, training, residual=None, update_moving=True, stats=None):
+        """stats: (records, records per group) from the producing convolution's epilogue (Conv3x3Bf16 / Conv2DBf16.forward_stats) --
+        one vcg_norm_finalize_partials launch then replaces the statistics pass over x and vcg_norm_finalize"""
         rt, ps, lib = self.rt, self.ps, self.rt.lib
         n, h, w, c = x.shape
         hw = h * w
@@ -920,7 +1007,18 @@ class NormActBf16(Layer):
         gamma = None if inst else ps[self.name + "/gamma"].data_ptr()
         beta = None if inst else ps[self.name + "/beta"].data_ptr()
         saved = None
-        if training or inst:
+        if (training or inst) and stats is not None:
+            buf, nrec = stats
+            mean = rt.empty(rows * c)
+            mm = mv = None
+            if not inst and update_moving:
+                mm, mv = ps[self.name + "/moving_mean"].data_ptr(), ps[self.name + "/moving_variance"].data_ptr()
+            L.check(lib.vcg_norm_finalize_partials(buf.data_ptr(), nrec, rows, c, float(hw if inst else n * hw), gamma, beta,
+                                                   IN_EPS if inst else BN_EPS, mean.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+                                                   invstd.data_ptr(), mm, mv, BN_MOMENTUM, 0 if inst else n * hw, rt.stream),
+                    "vcg_norm_finalize_partials[%s]" % self.name)
+            saved = (mean, invstd)
+        elif training or inst:
             mean, var = rt.empty(rows * c), rt.empty(rows * c)
             ws, wsn = rt.workspace(lib.vcg_norm_stats_bf16_workspace_bytes(n, c, hw, mode))
             L.check(lib.vcg_norm_stats_bf16(x.data_ptr(), n, c, hw, mode, mean.data_ptr(), var.data_ptr(), ws, wsn, rt.stream),

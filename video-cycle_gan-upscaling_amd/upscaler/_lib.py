@@ -34,8 +34,10 @@ FIRST9X9_WFRAG_BYTES = 27 * 64 * 2 * 16                # VCG_FIRST9X9_WFRAG_BYTE
 
 class EpilogueBf16(ctypes.Structure):
     _fields_ = [("scale", c_void_p), ("shift", c_void_p), ("act", c_int32), ("act_alpha", c_float),
-                ("prelu_alpha", c_void_p), ("residual", c_void_p)]
+                ("prelu_alpha", c_void_p), ("residual", c_void_p), ("stats", c_void_p), ("stats_mode", c_int32)]
 
+
+STATS_NONE, STATS_BATCH, STATS_INSTANCE = 0, 1, 2
 
 # name -> (restype, argtypes); every symbol include/vcg.h declares
 _P = c_void_p
@@ -57,6 +59,9 @@ SIGNATURES = {
     "vcg_norm_stats_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "vcg_norm_stats": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P, c_size_t, _P]),
     "vcg_norm_finalize": (c_int, [_P, _P, _P, _P, c_int, c_int, c_float, _P, _P, _P, _P, _P, c_float, c_int, _P]),
+    "vcg_sum_records": (c_int, [_P, c_int, c_int, c_float, _P, _P]),
+    "vcg_bn_fold": (c_int, [_P, _P, _P, _P, _P, c_int, c_float, _P, _P, _P]),
+    "vcg_norm_finalize_partials": (c_int, [_P, c_int, c_int, c_int, ctypes.c_double, _P, _P, c_float, _P, _P, _P, _P, _P, _P, c_float, c_int, _P]),
     "vcg_norm_act_fwd": (c_int, [_P, c_int, c_int, c_int, _P, _P, c_int, c_int, c_float, _P, _P, _P, _P]),
     "vcg_norm_act_bwd_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "vcg_norm_act_bwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_int, c_float, _P, c_int,
@@ -100,6 +105,7 @@ SIGNATURES = {
     "vcg_f32_nchw_to_bf16_nhwc": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
     "vcg_bf16_nhwc_to_f32_nchw": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
     "vcg_conv2d_bf16_fwd": (c_int, [_D, _P, _P, _P, _EB, _P]),
+    "vcg_conv2d_bf16_stats_records": (c_int, [_D, c_int32]),
     "vcg_conv_transpose2d_bf16_fwd": (c_int, [_D, _P, _P, _P, _EB, _P]),
     "vcg_norm_stats_bf16_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "vcg_norm_stats_bf16": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P, c_size_t, _P]),
@@ -114,6 +120,8 @@ SIGNATURES = {
     "vcg_pack_first9x9_bf16": (c_int, [_P, _P, _P]),
     "vcg_pack_conv9x9_3ch_bf16": (c_int, [_P, c_int, c_int, _P, _P]),
     "vcg_conv9x9_to3_bf16_dgrad": (c_int, [_D, _P, _P, _P, c_float, _P, _P]),
+    "vcg_conv9x9_to3_bf16_dgrad_chsum_records": (c_int, [_D]),
+    "vcg_conv9x9_to3_bf16_dgrad_chsum": (c_int, [_D, _P, _P, _P, c_float, _P, _P, _P]),
     "vcg_conv9x9_from3_bf16_fwd": (c_int, [_D, _P, _P, _P, _P, _P, _P]),
     "vcg_pack_final9x9_bf16": (c_int, [_P, _P, _P]),
     "vcg_conv9x9_to3_bf16_fwd": (c_int, [_D, _P, _P, _P, c_int, _P, _P]),
@@ -121,6 +129,8 @@ SIGNATURES = {
     "vcg_conv_frag_bf16_bytes": (c_size_t, [c_int, c_int, c_int]),
     "vcg_pack_conv_frag_bf16": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P]),
     "vcg_conv2d_nhwc_bf16_fwd": (c_int, [_D, _P, _P, _P, c_int, c_float, _P, _P]),
+    "vcg_conv2d_nhwc_bf16_stats_records": (c_int, [_D, c_int]),
+    "vcg_conv2d_nhwc_bf16_fwd_stats": (c_int, [_D, _P, _P, _P, _P, _P, _P]),
     "vcg_conv_transpose2d_nhwc_bf16_fwd": (c_int, [_D, _P, _P, _P, c_int, c_float, _P, _P]),
     "vcg_conv2d_nhwc_bf16_dgrad": (c_int, [_D, _P, _P, _P, c_float, _P, _P]),
     "vcg_conv2d_nhwc_bf16_wgrad_workspace_bytes": (c_size_t, [_D]),

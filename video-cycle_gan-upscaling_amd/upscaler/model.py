@@ -460,14 +460,27 @@ class UpscalerOrig(Model):
         if self.trunk_dtype == "bf16":          # the trunk (2*res+1 convolutions, norms, adds) on bf16 NHWC; fp32 outside
             h = E.to_bf16_nhwc(self.rt, h)
         skip = h
+        bf = self.trunk_dtype == "bf16"
+
+        def conv_norm(cv, nm, h, residual=None):
+            """conv -> norm[-> act][+ residual]; on the bf16 trunk the convolution's epilogue hands the norm its statistics, and in
+            learning phase 0 (predict) the whole group is one launch (BatchNormalization folded into the epilogue)"""
+            if bf and not training and nm.norm == "batch" and E.FOLD_PREDICT:
+                tape.extend((None, None))
+                return cv.forward_folded(h, nm, residual=residual, tag="trunk_conv")
+            if bf and nm.needs_stats(training):
+                h, a, st = cv.forward_stats(h, nm.norm == "instance", tag="trunk_conv"); tape.append(a)
+                h, a = nm.forward(h, training, residual=residual, stats=st); tape.append(a)
+            else:
+                h, a = cv.forward(h, tag="trunk_conv"); tape.append(a)
+                h, a = nm.forward(h, training, residual=residual); tape.append(a)
+            return h
+
         for (c1, n1, c2, n2) in self.blocks:
             gen = h
-            h, a = c1.forward(h, tag="trunk_conv"); tape.append(a)
-            h, a = n1.forward(h, training); tape.append(a)
-            h, a = c2.forward(h, tag="trunk_conv"); tape.append(a)
-            h, a = n2.forward(h, training, residual=gen); tape.append(a)
-        h, a = self.c_pre.forward(h, tag="trunk_conv"); tape.append(a)
-        h, a = self.n_pre.forward(h, training, residual=skip); tape.append(a)
+            h = conv_norm(c1, n1, h)
+            h = conv_norm(c2, n2, h, residual=gen)
+        h = conv_norm(self.c_pre, self.n_pre, h, residual=skip)
         if self.trunk_dtype == "bf16" and not self.tail_bf16:
             h = E.from_bf16_nhwc(self.rt, h)
         for u in self.ups:
@@ -482,8 +495,9 @@ class UpscalerOrig(Model):
         if self.tail_bf16:
             # final/conv's bf16 data gradient applies the up-sampling block's LeakyReLU derivative; the block's own gradients run
             # on the bf16 kernels and hand back bf16 NHWC, which is what the trunk's backward consumes
-            d = self.c_fin.backward(tape.pop(), dy, True, True, which, tag="final_conv", input_lrelu_slope=self.ups[-1].alpha)
-            d = self.ups[-1].backward(tape.pop(), d, True, True, which, tag="convt")
+            d, sums = self.c_fin.backward(tape.pop(), dy, True, True, which, tag="final_conv", input_lrelu_slope=self.ups[-1].alpha,
+                                          want_channel_sums=True)
+            d = self.ups[-1].backward(tape.pop(), d, True, True, which, tag="convt", dz_channel_sums=sums)
         else:
             d = self.c_fin.backward(tape.pop(), dy, True, True, which, tag="final_conv")
             for u in reversed(self.ups):
@@ -569,6 +583,10 @@ class DiscriminatorStack(Model):
         for i, (cv, na) in enumerate(self.convs):
             if bf and i == 1:
                 h = E.to_bf16_nhwc(rt, h)
+            if bf and i > 0 and na.needs_stats(training):
+                h, a, st = cv.forward_stats(h, False, tag="d_conv"); tape.append(a)
+                h, a = na.forward(h, training, update_moving=update_moving, stats=st); tape.append(a)
+                continue
             h, a = cv.forward(h, tag="d_conv"); tape.append(a)
             h, a = na.forward(h, training, update_moving=update_moving); tape.append(a)
         if bf and len(self.convs) > 1:
@@ -659,6 +677,10 @@ class DiscriminatorPatchGAN(Model):
                 h = E.to_bf16_nhwc(rt, h)
             if bf and i == last:
                 h = E.from_bf16_nhwc(rt, h)
+            if bf and na is not None and na.needs_stats(training):
+                h, a, st = cv.forward_stats(h, na.norm == "instance", tag="d_conv"); tape.append(a)
+                h, a = na.forward(h, training, update_moving=update_moving, stats=st); tape.append(a)
+                continue
             h, a = cv.forward(h, tag="d_conv"); tape.append(a)
             if na is not None:
                 h, a = na.forward(h, training, update_moving=update_moving); tape.append(a)
