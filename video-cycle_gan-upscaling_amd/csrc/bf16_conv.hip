@@ -1094,8 +1094,45 @@ struct F9Params {
     int tanh_act;
 };
 
+// Diagnostic build only (-DVCG_F9_STAMPS, scripts/micro/f9_stamps.sh): s_memtime brackets around the five segments of an input row, summed
+// per wave and written to a buffer of their own; no stamp executes in the shipped library.
+#ifdef VCG_F9_STAMPS
+__device__ unsigned long long vcg_f9_stamp_sums[512 * 4 * 8];
+#define F9_STAMP(t) V2_STAMP_RAW(t)
+#define F9_ADD(sum, a, b) sum += (b) - (a)
+#else
+#define F9_STAMP(t) do { } while (0)
+#define F9_ADD(sum, a, b) do { } while (0)
+#endif
+#define V2_STAMP_RAW(t)                                                               \
+    do {                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                            \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");     \
+        __builtin_amdgcn_sched_barrier(0);                                            \
+    } while (0)
+
+// tanh from one v_exp_f32 and one v_rcp_f32 (tanhf's libm expansion was ~100 instructions per output value on the three waves that
+// finish a row while the fourth idles): 1 - 2 / (exp(2|x|) + 1), odd; below 2^-6 the cubic, where the quotient form would cancel.
+// Absolute error < 2e-7, far below the bf16 operands' own rounding.
+__device__ __forceinline__ float fast_tanh(float x) {
+    const float a = fabsf(x);
+    const float t = 1.f - 2.f * __frcp_rn(__expf(2.f * a) + 1.f);
+    const float small = a * (1.f - a * a * (1.f / 3.f));
+    return copysignf(a < 0.015625f ? small : t, x);
+}
+
+// BUF: the row slices are fetched through the image's buffer descriptor (pixels outside the image read as zero by the range check) with two
+// lane constants; the pointer form (BUF = false: images too large for a descriptor) keeps nine 64-bit lane addresses, which at this kernel's
+// 256-register budget are SPILLED -- hipcc then waits vmcnt(0) in front of every reload, i.e. for every earlier piece of the row: the nine
+// pieces went out one HBM round trip after the other, 8.0 k of the 15.4 k cycles of a row (profiles/r03_f9_stamps.txt).
+template <bool BUF>
 __global__ __launch_bounds__(256, 2) void conv9x9_c256to3_bf16_kernel(F9Params p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned long long f0 = 0, f1 = 0, f2 = 0, f3 = 0, f4 = 0, f5 = 0, f6 = 0, fs_shift = 0, fs_wait = 0, fs_dma = 0, fs_mfma = 0, fs_bar = 0, fs_out = 0, f_rows = 0;
+    (void)f6, (void)fs_shift, (void)f0, (void)f1, (void)f2, (void)f3, (void)f4, (void)f5, (void)fs_wait, (void)fs_dma, (void)fs_mfma, (void)fs_bar, (void)fs_out, (void)f_rows;
+#ifdef VCG_F9_STAMPS
+    const unsigned long long k_c0 = __builtin_amdgcn_s_memtime(), k_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, hh = lane >> 5;
     const int c = __builtin_amdgcn_readfirstlane(tid >> 6);          // wave = input-channel chunk
     unsigned char* rowbuf = smem + c * 2 * F_ROWB;
@@ -1123,12 +1160,32 @@ __global__ __launch_bounds__(256, 2) void conv9x9_c256to3_bf16_kernel(F9Params p
     const int l3 = lane >> 3, l4 = lane >> 4, l7 = lane & 7;
     const float bias = (p.bias && tid < 192) ? p.bias[tid >> 6] : 0.f;
     const unsigned char* zeros = (const unsigned char*)(p.wfrag + F_NFRAG);      // padding pixels are fetched from here
+    // BUF: byte offset of this lane's slot of piece k relative to the piece's first pixel: pixel l3, source chunk of parity k & 1
+    unsigned lc[2];
+#pragma unroll
+    for (int par = 0; par < 2; ++par) lc[par] = (unsigned)(l3 * 512 + (c * 8 + (l7 ^ ((4 * par + l4) & 7))) * 16);
+    const long img_bytes = (long)p.h * p.w_ * 512;
 
     for (int item = blockIdx.x; item < p.total; item += gridDim.x) {
         const int seg = item % p.segs, i2 = item / p.segs, strip = i2 % p.strips, img = i2 / p.strips;
         const int x0 = strip * 64, y0 = seg * p.sh, y1 = min(y0 + p.sh, p.h);
+        const vcg_rsrc rs = make_rsrc(p.x + img * img_bytes, (unsigned long)img_bytes);
 
         auto dma = [&](int yi, int buf) {
+            if (BUF) {
+                // offset = (row, first pixel of the strip's halo) + piece + lane constant, in 32-bit wrap-around arithmetic: a row above the
+                // image lands just below 4 GiB, a row below it just past the image -- both outside the descriptor (host guard)
+                const unsigned row_off = (unsigned)(yi * p.w_ + x0 - 4) * 512u;
+#pragma unroll
+                for (int k = 0; k < 9; ++k) {
+                    const int gx = x0 - 4 + k * 8 + l3;
+                    unsigned off = row_off + (unsigned)(k * 4096) + lc[k & 1];
+                    asm volatile("" : "+v"(off));                    // a select, not a branch around the arithmetic
+                    off = (unsigned)gx < (unsigned)p.w_ ? off : VCG_OOB;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (void __attribute__((address_space(3)))*)(rowbuf + buf * F_ROWB + k * 1024), 16, off, 0, 0, 0);
+                }
+                return;
+            }
             const bool rowok = (unsigned)yi < (unsigned)p.h;
             const unsigned char* rowp = p.x + ((long)(img * p.h + (rowok ? yi : 0)) * p.w_) * 512;
 #pragma unroll
@@ -1151,39 +1208,44 @@ __global__ __launch_bounds__(256, 2) void conv9x9_c256to3_bf16_kernel(F9Params p
         dma(y0 - 4, 0);
         for (int yi = y0 - 4; yi < y1 + 4; ++yi) {
             const int buf = (yi - (y0 - 4)) & 1;
+            F9_STAMP(f0);
             __builtin_amdgcn_s_waitcnt(0x0F70);              // vmcnt(0): this row's slice has landed in LDS
             asm volatile("" ::: "memory");
+            F9_STAMP(f1);
             if (yi + 1 < y1 + 4) dma(yi + 1, buf ^ 1);
             const unsigned char* xb = rowbuf + buf * F_ROWB;
+            F9_STAMP(f6);
 
-            // shift the partial sums by one ky group and use them as the C operand
+            // shift the partial sums by one ky group and use them as the C operand.  Register by register, carrying the previous group's
+            // upper halves: three temporaries instead of 32 (with all 16 swaps first the kernel spilled, and every scratch reload behind
+            // an LDS-DMA costs a vmcnt(0))
 #pragma unroll
             for (int tt = 0; tt < 2; ++tt) {
-                float lo[16], hi[16];
-#pragma unroll
-                for (int j = 0; j < 16; ++j) {
-                    float a = acc[tt][j], b = acc[tt][j];
-                    swap32(a, b);                            // a = (lower, lower), b = (upper, upper)
-                    lo[j] = a;
-                    hi[j] = b;
-                }
+                float ph[3] = {0.f, 0.f, 0.f};                   // upper halves of the previous group (group 2jq-1 -> 2jq)
 #pragma unroll
                 for (int jq = 0; jq < 4; ++jq)
 #pragma unroll
                     for (int sl = 0; sl < 3; ++sl) {
-                        const float from_prev = jq > 0 ? hi[4 * (jq - 1) + sl] : 0.f;       // group 2jq-1 -> 2jq
-                        acc[tt][4 * jq + sl] = hh ? lo[4 * jq + sl] : from_prev;            // group 2jq -> 2jq+1
+                        float a = acc[tt][4 * jq + sl], b = a;
+                        swap32(a, b);                            // a = (lower, lower), b = (upper, upper)
+                        acc[tt][4 * jq + sl] = hh ? a : ph[sl];  // group 2jq -> 2jq+1
+                        ph[sl] = b;
                     }
-                acc[tt][3] = hh ? hi[13] : hi[12];           // rows 3 / 7  <- group 7, co 0 / 1
-                acc[tt][7] = hh ? 0.f : hi[14];              // row 11      <- group 7, co 2
+                acc[tt][3] = hh ? ph[1] : ph[0];                 // rows 3 / 7  <- group 7, co 0 / 1
+                acc[tt][7] = hh ? 0.f : ph[2];                   // row 11      <- group 7, co 2
                 acc[tt][11] = 0.f;
                 acc[tt][15] = 0.f;
             }
 
+            F9_STAMP(f2);
             bf16x8 fb[2][2];
+            // an opaque zero in every fragment address: without it hipcc hoists all 36 (kx, s) addresses out of the row loop and keeps them
+            // live in 36 registers -- this kernel has 9 to give (144 of its 256 hold the weights) and spilled the rest
+            int opq = 0;
+            asm volatile("" : "+v"(opq));
             auto frag = [&](auto ic) {
                 constexpr int i = decltype(ic)::value, kx = i >> 2, s = i & 3, bq = i & 1;
-                const unsigned char* a = xb + (T[kx] ^ (s << 5));
+                const unsigned char* a = xb + ((T[kx] + opq) ^ (s << 5));
                 fb[bq][0] = *(const bf16x8*)(a);
                 fb[bq][1] = *(const bf16x8*)(a + 32 * 128);
             };
@@ -1197,31 +1259,45 @@ __global__ __launch_bounds__(256, 2) void conv9x9_c256to3_bf16_kernel(F9Params p
                 __builtin_amdgcn_sched_barrier(0);
             });
 
+            F9_STAMP(f3);
             // finished output row yo = yi - 4: this wave's partial (its 64 input channels) -> LDS
             const int yo = yi - 4, slot = yo & 1;
             if (yo >= y0) {
                 float* pp = part + ((slot * 4 + c) * 3) * 64;
 #pragma unroll
                 for (int tt = 0; tt < 2; ++tt) {
-                    if (hh == 0) {
-                        pp[0 * 64 + tt * 32 + r] = acc[tt][3];
-                        pp[2 * 64 + tt * 32 + r] = acc[tt][7];
-                    } else {
-                        pp[1 * 64 + tt * 32 + r] = acc[tt][3];
-                    }
+                    // rows 3 / 7 / 11 = co 0 (lower half) / 1 (upper half) / 2 (lower half): every lane stores register 3 to its co's row, the
+                    // lower half register 7 as well (written as selects: hipcc turned the two-sided branch into a 16-way register select)
+                    pp[hh * 64 + tt * 32 + r] = acc[tt][3];
+                    if (hh == 0) pp[2 * 64 + tt * 32 + r] = acc[tt][7];
                 }
             }
-            lds_barrier();
+            // the partial sums are ordinary LDS stores: wait for them and meet.  NOT lds_barrier(): its fence makes hipcc drain vmcnt(0),
+            // i.e. wait here for the NEXT row's slice, which nothing reads before the wait at the top of the next iteration
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            F9_STAMP(f4);
             if (yo >= y0 && tid < 192) {
                 const int co = tid >> 6, col = tid & 63;
                 const float* q = part + slot * 4 * 3 * 64 + co * 64 + col;
                 float v = ((q[0] + q[3 * 64]) + (q[2 * 3 * 64] + q[3 * 3 * 64])) + bias;
-                if (p.tanh_act) v = tanhf(v);
+                if (p.tanh_act) v = fast_tanh(v);
                 if (x0 + col < p.w_) p.y[((long)(img * 3 + co) * p.h + yo) * p.w_ + x0 + col] = v;
             }
+            F9_STAMP(f5);
+            F9_ADD(fs_wait, f0, f1); F9_ADD(fs_dma, f1, f6); F9_ADD(fs_shift, f6, f2); F9_ADD(fs_mfma, f2, f3); F9_ADD(fs_bar, f3, f4); F9_ADD(fs_out, f4, f5);
+            F9_ADD(f_rows, 0ull, 1ull);
         }
         lds_barrier();       // the next item's first partial slot / row buffers are free
     }
+#ifdef VCG_F9_STAMPS
+    if (lane == 0 && blockIdx.x < 512) {
+        unsigned long long* o = vcg_f9_stamp_sums + (blockIdx.x * 4 + c) * 8;
+        o[0] = fs_wait, o[1] = fs_dma, o[2] = fs_mfma, o[3] = fs_bar, o[4] = fs_out, o[5] = f_rows;
+        o[6] = __builtin_amdgcn_s_memtime() - k_c0, o[7] = fs_shift;
+    }
+#endif
 }
 
 __global__ void pack_final9x9_kernel(const float* __restrict__ w, uint4* __restrict__ out) {
@@ -1454,19 +1530,35 @@ int vcg_conv9x9_to3_bf16_fwd(const vcg_conv_desc* d, const void* x, const void* 
     p.h = d->h;
     p.w_ = d->w;
     p.strips = ceil_div(d->w, 64);
-    p.sh = 128;                                   // shorter segments (more halo recompute) until the chip is filled twice
-    while (p.sh > 32 && p.n * p.strips * ceil_div(d->h, p.sh) < 1024) p.sh >>= 1;
-    p.segs = ceil_div(d->h, p.sh);
+    static const int max_grid = getenv("VCG_F9_GRID") ? atoi(getenv("VCG_F9_GRID")) : 512;      // tuning aid (scripts/micro/f9_stamps.py)
+    // segments per column strip: the split that minimises the rows the busiest workgroup marches through -- rounds of items per
+    // workgroup x (segment height + 8 recomputed halo rows).  (Round 2 halved the height until the items filled the grid twice: 25 % halo
+    // rows at C3's shape, and at C4's 1080 items on 512 workgroups = a third round for 56 of them.)
+    {
+        long best = -1;
+        const int colstrips = p.n * p.strips;
+        for (int segs = 1; segs <= ceil_div(d->h, 16); ++segs) {
+            const int sh = ceil_div(d->h, segs);
+            if (ceil_div(d->h, sh) != segs) continue;                             // (the same height reached with fewer segments)
+            const long items = (long)colstrips * segs, rounds = (items + max_grid - 1) / max_grid, cost = rounds * (sh + 8);
+            if (best < 0 || cost < best) { best = cost; p.sh = sh; p.segs = segs; }
+        }
+    }
     p.total = p.n * p.strips * p.segs;
     p.tanh_act = tanh_act;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv9x9_c256to3_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS);
+        hipError_t e = hipFuncSetAttribute((const void*)conv9x9_c256to3_bf16_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS);
+        if (e != hipSuccess) return (int)e;
+        e = hipFuncSetAttribute((const void*)conv9x9_c256to3_bf16_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    const int grid = p.total < 512 ? p.total : 512;
-    conv9x9_c256to3_bf16_kernel<<<grid, 256, F_LDS, stream>>>(p);
+    const int grid = p.total < max_grid ? p.total : max_grid;
+    // the descriptor form needs the image, four rows above and four below it inside 32-bit offsets
+    const bool buf = ((long)d->h + 8) * d->w * 512 + 65536 <= 0xFFFFFFE0l && getenv("VCG_F9_PTR") == nullptr;
+    if (buf) conv9x9_c256to3_bf16_kernel<true><<<grid, 256, F_LDS, stream>>>(p);
+    else conv9x9_c256to3_bf16_kernel<false><<<grid, 256, F_LDS, stream>>>(p);
     VCG_LAUNCH_CHECK();
     return VCG_OK;
 }
@@ -1570,6 +1662,12 @@ int vcg_conv9x9_to3_bf16_dgrad_chsum(const vcg_conv_desc* d, const void* dy, con
 
 }  // extern "C"
 
+#ifdef VCG_F9_STAMPS
+extern "C" int vcg_debug_f9_stamps(unsigned long long* host_out) {
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(vcg_f9_stamp_sums), sizeof(unsigned long long) * 512 * 4 * 8);
+}
+#endif
 #ifdef VCG_V2_STAMPS
 // diagnostic build only: copy the per-wave sums [256 workgroups][4 waves][phase A, phase B, vmcnt wait, barrier, kernel core clocks, kernel 100-MHz ticks] to the host
 extern "C" int vcg_debug_v2_stamps(unsigned long long* host_out) {

@@ -245,7 +245,8 @@ __global__ __launch_bounds__(256) void norm_bwd_partial_bf16_kernel(const bf16x8
 
 // group sums [groups*c][2]; block = (group, 64 channels), 16 row groups sum the slabs, fixed-order combine
 __global__ __launch_bounds__(1024) void norm_bwd_sums_bf16_kernel(const float* __restrict__ part, int c, int slabs_per_group, int groups,
-                                                                   float* __restrict__ sums, float* __restrict__ gsum) {
+                                                                   float* __restrict__ sums, float* __restrict__ gsum, float* __restrict__ dgamma,
+                                                                   float* __restrict__ dbeta, float* __restrict__ dalpha) {
     __shared__ double r1[16][64], r2[16][64], r3[16][64];
     const int cblocks = (c + 63) / 64, grp = blockIdx.x / cblocks, ch = (blockIdx.x - grp * cblocks) * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
     double s1 = 0.0, s2 = 0.0, s3 = 0.0;
@@ -277,6 +278,12 @@ __global__ __launch_bounds__(1024) void norm_bwd_sums_bf16_kernel(const float* _
     for (int i = 1; i < 16; ++i) { s1 += r1[i][threadIdx.x]; s2 += r2[i][threadIdx.x]; s3 += r3[i][threadIdx.x]; }
     sums[((long)grp * c + ch) * 2] = (float)s1;
     sums[((long)grp * c + ch) * 2 + 1] = (float)s2;
+    if (groups == 1) {                                    // batch statistics: the group totals ARE the parameter gradients (no second kernel)
+        if (dbeta) dbeta[ch] = (float)s1;
+        if (dgamma) dgamma[ch] = (float)s2;
+        if (dalpha) dalpha[ch] = (float)s3;
+        return;
+    }
     float* gs = gsum + ((long)grp * c + ch) * 3;          // per-group totals for the parameter gradients
     gs[0] = (float)s1;
     gs[1] = (float)s2;
@@ -424,9 +431,9 @@ int vcg_norm_act_bwd_bf16(const void* x, const void* dy, int n, int c, int hw, i
                                                                                            mean, invstd, gamma, beta, act, act_alpha, prelu_alpha, bpg, part);
     VCG_LAUNCH_CHECK();
     float* gsum = sums + (size_t)groups * c * 2;
-    norm_bwd_sums_bf16_kernel<<<groups * ceil_div(c, 64), 1024, 0, stream>>>(part, c, bpg, groups, sums, gsum);
+    norm_bwd_sums_bf16_kernel<<<groups * ceil_div(c, 64), 1024, 0, stream>>>(part, c, bpg, groups, sums, gsum, dgamma, dbeta, dprelu_alpha);
     VCG_LAUNCH_CHECK();
-    if (dgamma || dbeta || dprelu_alpha) {
+    if (groups > 1 && (dgamma || dbeta || dprelu_alpha)) {
         norm_bwd_params_bf16_kernel<<<ceil_div(c, 64), 64, 0, stream>>>(gsum, c, groups, dgamma, dbeta, dprelu_alpha);
         VCG_LAUNCH_CHECK();
     }

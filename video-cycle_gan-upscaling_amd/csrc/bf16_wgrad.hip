@@ -98,28 +98,42 @@ __global__ __launch_bounds__(G_NW * 64, 1) void wgrad3x3_c64_bf16_kernel(WgParam
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[a][b][c][e] = 0.f;
 
+    const long img_bytes = (long)p.h * p.w_ * 128;
     auto dma = [&](int tile, int buf) {
         const int txi = tile % p.tiles_x, t2 = tile / p.tiles_x, tyi = t2 % p.tiles_y, img = t2 / p.tiles_y;
         const int y0 = tyi * G_R, x0 = txi * G_C;
-        // The slot -> address arithmetic is redone for every tile on purpose: hoisted out of the tile loop it costs 40
-        // VGPRs the kernel does not have (192 are accumulators), the spills come back as scratch loads, and a scratch load
-        // shares vmcnt with the DMA -- every reload would wait for the previous global_load_lds to land (measured: 8x slower)
-        int tid_o = tid;
-        asm volatile("" : "+v"(tid_o));
+        // Thirteen 1-KiB pieces per wave and stage.  What the address arithmetic may cost is set by the 96 MFMAs of a tile: round 2
+        // decoded every slot from a spilled copy of threadIdx (a scratch reload + vmcnt(0) per tile) through per-lane branches --
+        // about a thousand instructions per tile.  Here a piece's first slot k*384 + wv*64 is wave-uniform, so dy or x, and for dy the
+        // row, are scalar; the lane id is re-read from mbcnt (no register held across the tile loop); out-of-image pixels get the
+        // out-of-range offset of the image's buffer descriptor (zero fill by the range check: no zero page, no 64-bit lane pointers).
+        const vcg_rsrc rdy = make_rsrc(p.dy + img * img_bytes, (unsigned long)img_bytes), rx = make_rsrc(p.x + img * img_bytes, (unsigned long)img_bytes);
+        int ln = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)), wvo = wv;
+        asm volatile("" : "+v"(ln), "+s"(wvo));        // opaque: hoisted out of the tile loop this arithmetic holds ~40 registers the kernel
+        //                                               does not have (192 are accumulators); a spilled one comes back as a scratch load,
+        //                                               which shares vmcnt with the DMA: every reload waits for the pieces before it
+        const int l3 = ln >> 3, l7 = ln & 7;
+        const unsigned cs16 = (unsigned)((l7 ^ (4 * ((l3 >> 1) & 1))) * 16);       // stored chunk l7 holds source chunk l7 ^ 4*((pixel >> 1) & 1)
 #pragma unroll
         for (int k = 0; k < G_NDMA; ++k) {
-            const int s = min(k * (G_NW * 64) + tid_o, G_CHUNKS - 1);        // the tail re-fetches the last chunk into its own slot
-            const bool isx = s >= G_DYB / 16;
-            const int sl = isx ? s - G_DYB / 16 : s;
-            const int P = sl >> 3, cs = (sl & 7) ^ (4 * ((P >> 1) & 1));     // stored chunk (sl&7) holds source chunk cs
-            const int row = isx ? P / G_XP : P >> 5, col = isx ? P - row * G_XP : P & 31;
-            const int gy = y0 + row - (isx ? 1 : 0), gx = x0 + col - (isx ? 1 : 0);
-            const bool ok = (unsigned)gy < (unsigned)p.h && (unsigned)gx < (unsigned)p.w_;
-            const unsigned char* base = isx ? p.x : p.dy;
-            const unsigned char* src = ok ? base + ((long)(img * p.h + gy) * p.w_ + gx) * 128 + cs * 16 : (const unsigned char*)vcg_zero_word;
-            // lanes of one instruction must write consecutive 16-byte slots: slot index = k*384 + tid
-            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src,
-                                             (void __attribute__((address_space(3)))*)(smem + buf * G_BUF + (k * (G_NW * 64) + wv * 64) * 16), 16, 0, 0);
+            const int sb = k * (G_NW * 64) + wvo * 64;                            // first slot of this wave's piece: a multiple of 64
+            void __attribute__((address_space(3)))* dst = (void __attribute__((address_space(3)))*)(smem + buf * G_BUF + sb * 16);
+            if (sb < G_DYB / 16) {
+                // dy tile [8][32] pixels: the piece is 8 consecutive pixels of ONE row
+                const int m = sb >> 6, gy = y0 + (m >> 2), xb = x0 + (m & 3) * 8;
+                unsigned off = (unsigned)((gy * p.w_ + xb) * 128) + (unsigned)(l3 * 128) + cs16;
+                asm volatile("" : "+v"(off));
+                off = (gy < p.h && xb + l3 < p.w_) ? off : VCG_OOB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rdy, dst, 16, off, 0, 0, 0);
+            } else {
+                // x halo tile [10][34] pixels: 8 consecutive pixels, possibly across a row end; P / 34 by multiplication (exact below 340)
+                const int P = ((sb - G_DYB / 16) >> 3) + l3, row = (P * 241) >> 13, col = P - row * G_XP;
+                const int gy = y0 + row - 1, gx = x0 + col - 1;
+                unsigned off = (unsigned)((gy * p.w_ + gx) * 128) + cs16;
+                asm volatile("" : "+v"(off));
+                off = ((unsigned)gy < (unsigned)p.h && (unsigned)gx < (unsigned)p.w_ && P < (G_R + 2) * G_XP) ? off : VCG_OOB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, dst, 16, off, 0, 0, 0);
+            }
         }
     };
 
@@ -214,50 +228,45 @@ __global__ __launch_bounds__(G_NW * 64, 1) void wgrad3x3_c64_bf16_kernel(WgParam
     }
 }
 
-// dW[tap = dyi*3+dx][ci][co] = sum over workgroups, in a fixed order.  One thread per element of a tap row's raw block (reads
-// coalesced in the dump's own order), the decoded (tap, ci, co) position is only used for the single store.
-__global__ void wgrad3x3_c64_reduce_kernel(const float* __restrict__ ws, int nblocks, float* __restrict__ dw) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;             // (dyi, raw offset)
-    if (idx >= 3 * G_WAVE_FLOATS) return;
-    const int dyi = idx / G_WAVE_FLOATS, off = idx - dyi * G_WAVE_FLOATS;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int b = 0;
-    for (; b + 7 < nblocks; b += 8) {                                   // eight partial blocks in flight per thread, fixed order
+// dW[tap = dyi*3+dx][ci][co] = sum over workgroups, in a fixed order; the decoded (tap, ci, co) position is only used for the single store.
+// Both tails in ONE launch: block = 64 columns x 16 record lanes (eight records in flight per thread), blocks [0, 576) sum the partial
+// weight blocks of their 64 raw columns, block 576 the 4 x grid partial bias rows (round 2 ran two kernels, 14 + 10 us per weight
+// gradient on 144 workgroups and on one).
+__global__ __launch_bounds__(1024) void wgrad3x3_c64_reduce2_kernel(const float* __restrict__ ws, const float* __restrict__ wsb, int nblocks,
+                                                                     float* __restrict__ dw, float* __restrict__ db) {
+    __shared__ float red[16][64];
+    constexpr int NMAIN = 3 * G_WAVE_FLOATS / 64;
+    const int g = threadIdx.x >> 6, cl = threadIdx.x & 63;
+    const bool main_blk = (int)blockIdx.x < NMAIN;
+    const int idx = blockIdx.x * 64 + cl, dyi = main_blk ? idx / G_WAVE_FLOATS : 0, off = idx - dyi * G_WAVE_FLOATS;
+    const float* src = main_blk ? ws + (long)dyi * G_WAVE_FLOATS + off : wsb + cl;
+    const long stride = main_blk ? 3l * G_WAVE_FLOATS : 64l;
+    const int nrec = main_blk ? nblocks : nblocks * 4;
+    if (!main_blk && db == nullptr) return;
+    float s = 0.f;
+    int b = g;
+    for (; b + 16 * 7 < nrec; b += 16 * 8) {
         float v[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = ws[((long)(b + u) * 3 + dyi) * G_WAVE_FLOATS + off];
-        s0 += v[0]; s1 += v[1]; s2 += v[2]; s3 += v[3];
-        s0 += v[4]; s1 += v[5]; s2 += v[6]; s3 += v[7];
+        for (int u = 0; u < 8; ++u) v[u] = src[(long)(b + 16 * u) * stride];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
     }
-    for (; b < nblocks; ++b) s0 += ws[((long)b * 3 + dyi) * G_WAVE_FLOATS + off];
+    for (; b < nrec; b += 16) s += src[(long)b * stride];
+    red[g][cl] = s;
+    __syncthreads();
+    if (g != 0) return;
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) t += red[i][cl];
+    if (!main_blk) {
+        db[cl] = t;
+        return;
+    }
     // raw offset -> tile (dx, ci half, co half), register e, lane l;  D[row][col]: row = (e&3) + 8*(e>>2) + 4*(l>>5), col = l&31
     const int l = off & 63, e = (off >> 6) & 15, tile = off >> 10, coh = tile & 1, cih = (tile >> 1) & 1, dx = tile >> 2;
     const int co = 32 * coh + (e & 3) + 8 * (e >> 2) + 4 * (l >> 5), ci = 32 * cih + (l & 31);
-    dw[((dyi * 3 + dx) * 64 + ci) * 64 + co] = (s0 + s1) + (s2 + s3);
-}
-
-__global__ __launch_bounds__(1024) void wgrad3x3_c64_bias_reduce_kernel(const float* __restrict__ wsb, int nblocks, float* __restrict__ db) {
-    // 16 row groups x 64 channels; fixed order within a group and across groups
-    __shared__ float red[16][64];
-    const int c = threadIdx.x & 63, g = threadIdx.x >> 6, rows = nblocks * 4;
-    float s = 0.f;
-    int b = g;
-    for (; b + 48 < rows; b += 64) {                                    // four rows in flight per thread (a single workgroup: latency-bound otherwise)
-        float v[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) v[u] = wsb[(long)(b + 16 * u) * 64 + c];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) s += v[u];
-    }
-    for (; b < rows; b += 16) s += wsb[(long)b * 64 + c];
-    red[g][c] = s;
-    __syncthreads();
-    if (g == 0) {
-        float t = 0.f;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) t += red[i][c];
-        db[c] = t;
-    }
+    dw[((dyi * 3 + dx) * 64 + ci) * 64 + co] = t;
 }
 
 constexpr int G_GRID = 256;
@@ -282,6 +291,7 @@ int vcg_conv2d_bf16_wgrad(const vcg_conv_desc* d, const void* x, const void* dy,
     p.dy = (const unsigned char*)dy;
     p.ws = (float*)ws;
     p.wsb = (float*)ws + (size_t)G_GRID * 3 * G_WAVE_FLOATS;
+    if ((long)d->h * d->w * 128 > 0xFFFFFFE0l) return VCG_E_UNSUPPORTED;        // an image behind one buffer descriptor
     p.n = d->n; p.h = d->h; p.w_ = d->w;
     p.tiles_x = ceil_div(d->w, G_C);
     p.tiles_y = ceil_div(d->h, G_R);
@@ -295,12 +305,9 @@ int vcg_conv2d_bf16_wgrad(const vcg_conv_desc* d, const void* x, const void* dy,
     const int grid = p.total < G_GRID ? p.total : G_GRID;
     wgrad3x3_c64_bf16_kernel<<<grid, G_NW * 64, 2 * G_BUF, stream>>>(p);
     VCG_LAUNCH_CHECK();
-    wgrad3x3_c64_reduce_kernel<<<(3 * G_WAVE_FLOATS + 255) / 256, 256, 0, stream>>>((const float*)ws, grid, dw_hwio);
+    static_assert(G_WAVE_FLOATS % 64 == 0, "wgrad3x3 reduce: 64 raw columns per block stay inside one tap row");
+    wgrad3x3_c64_reduce2_kernel<<<3 * G_WAVE_FLOATS / 64 + 1, 1024, 0, stream>>>((const float*)ws, p.wsb, grid, dw_hwio, dbias);
     VCG_LAUNCH_CHECK();
-    if (dbias) {
-        wgrad3x3_c64_bias_reduce_kernel<<<1, 1024, 0, stream>>>(p.wsb, grid, dbias);
-        VCG_LAUNCH_CHECK();
-    }
     return VCG_OK;
 }
 

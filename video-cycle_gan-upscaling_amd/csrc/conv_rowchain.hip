@@ -91,17 +91,27 @@ __global__ __launch_bounds__(R_NW * 64, 1) void conv9x9_rowchain_f32_kernel(RowC
         const int x0 = strip * 64, y0 = seg * p.sh, y1 = min(y0 + p.sh, p.h);
         const float* xin = p.x + ((long)img * 256 + c * R_CI) * plane;
 
+        // The wave's [32 channels][72 columns] slice of a row, nine 1-KiB pieces through the slab's buffer descriptor.  The lane's chunk
+        // (channel slot/18, columns 4*(slot%18)..+3) is recomputed per row from an opaque lane index: nine hoisted 64-bit lane pointers
+        // were SPILLED at this kernel's 256-register budget, and hipcc waits vmcnt(0) in front of every scratch reload -- i.e. for every
+        // piece issued before it: the pieces went out one HBM round trip after the other (the same defect, measured, in
+        // bf16_conv.hip: conv9x9_c256to3_bf16_kernel, profiles/r03_f9_stamps.txt).
+        const vcg_rsrc rs = make_rsrc(xin, (size_t)R_CI * plane * 4);
         auto dma = [&](int yi, int buf) {
             const bool rowok = (unsigned)yi < (unsigned)p.h;
+            int ln = lane;
+            asm volatile("" : "+v"(ln));
+            const unsigned row_off = (unsigned)(yi * p.w_ + x0 - 4) * 4u;
 #pragma unroll
             for (int k = 0; k < 9; ++k) {
-                const int slot = k * 64 + lane;                // 16-byte chunk: channel slot/18, columns 4*(slot%18)..+3
+                const int slot = k * 64 + ln;
                 const int cl = slot / 18, ch = slot - cl * 18;
                 const int gx = x0 - 4 + 4 * ch;
                 const bool ok = rowok && gx >= 0 && gx + 3 < p.w_;
-                const float* src = ok ? xin + cl * plane + (long)yi * p.w_ + gx : vcg_zero_word;
-                __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src,
-                                                 (void __attribute__((address_space(3)))*)(rowbuf + buf * R_ROWB + k * 1024), 16, 0, 0);
+                unsigned off = row_off + (unsigned)cl * (unsigned)(plane * 4) + (unsigned)(ch * 16);
+                asm volatile("" : "+v"(off));                   // a select, not a branch around the arithmetic
+                off = ok ? off : VCG_OOB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (void __attribute__((address_space(3)))*)(rowbuf + buf * R_ROWB + k * 1024), 16, off, 0, 0, 0);
             }
         };
 
@@ -119,26 +129,22 @@ __global__ __launch_bounds__(R_NW * 64, 1) void conv9x9_rowchain_f32_kernel(RowC
             if (yi + 1 < y1 + 4) dma(yi + 1, buf ^ 1);
             const unsigned char* xb = rowbuf + buf * R_ROWB + bbase;
 
-            // shift the partial sums by one ky group; they become the C operand of this row's MFMAs
+            // shift the partial sums by one ky group; they become the C operand of this row's MFMAs.  Register by register, carrying the
+            // previous group's upper halves (three temporaries, not 32: the kernel has no registers to spare)
 #pragma unroll
             for (int tt = 0; tt < 2; ++tt) {
-                float lo[16], hi[16];
-#pragma unroll
-                for (int j = 0; j < 16; ++j) {
-                    float a = acc[tt][j], b = acc[tt][j];
-                    swap32(a, b);                              // a = (lower, lower), b = (upper, upper)
-                    lo[j] = a;
-                    hi[j] = b;
-                }
+                float ph3[3] = {0.f, 0.f, 0.f};
 #pragma unroll
                 for (int jq = 0; jq < 4; ++jq)
 #pragma unroll
                     for (int s3 = 0; s3 < 3; ++s3) {
-                        const float from_prev = jq > 0 ? hi[4 * (jq - 1) + s3] : 0.f;        // group 2jq-1 -> 2jq
-                        acc[tt][4 * jq + s3] = hh ? lo[4 * jq + s3] : from_prev;             // group 2jq -> 2jq+1
+                        float a = acc[tt][4 * jq + s3], b = a;
+                        swap32(a, b);                              // a = (lower, lower), b = (upper, upper)
+                        acc[tt][4 * jq + s3] = hh ? a : ph3[s3];   // group 2jq -> 2jq+1; group 2jq-1 -> 2jq
+                        ph3[s3] = b;
                     }
-                acc[tt][3] = hh ? hi[13] : hi[12];             // rows 3 / 7  <- group 7, co 0 / 1
-                acc[tt][7] = hh ? 0.f : hi[14];                // row 11      <- group 7, co 2
+                acc[tt][3] = hh ? ph3[1] : ph3[0];             // rows 3 / 7  <- group 7, co 0 / 1
+                acc[tt][7] = hh ? 0.f : ph3[2];                // row 11      <- group 7, co 2
                 acc[tt][11] = 0.f;
                 acc[tt][15] = 0.f;
             }
@@ -167,15 +173,16 @@ __global__ __launch_bounds__(R_NW * 64, 1) void conv9x9_rowchain_f32_kernel(RowC
                 float* pp = part + ((slot * R_NW + c) * 3) * 64;
 #pragma unroll
                 for (int tt = 0; tt < 2; ++tt) {
-                    if (hh == 0) {
-                        pp[0 * 64 + tt * 32 + r] = acc[tt][3];
-                        pp[2 * 64 + tt * 32 + r] = acc[tt][7];
-                    } else {
-                        pp[1 * 64 + tt * 32 + r] = acc[tt][3];
-                    }
+                    // rows 3 / 7 / 11 = co 0 (lower half) / 1 (upper half) / 2 (lower half)
+                    pp[hh * 64 + tt * 32 + r] = acc[tt][3];
+                    if (hh == 0) pp[2 * 64 + tt * 32 + r] = acc[tt][7];
                 }
             }
-            lds_barrier();
+            // the partial sums are ordinary LDS stores: wait for them and meet.  NOT lds_barrier(): its fence makes hipcc drain vmcnt(0),
+            // i.e. wait here for the NEXT row's slice, which nothing reads before the wait at the top of the next iteration
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
             if (yo >= y0 && tid < 192) {
                 const int oc = tid >> 6, col = tid & 63;
                 if (oc < p.cout) {
@@ -197,13 +204,22 @@ int vcg_internal_conv9_rowchain(const float* x, const float* w, float* y, int n,
                                 int ws_t, int ws_m, int ws_k, hipStream_t st) {
     if (cin != 256 || cout < 1 || cout > 3 || (wd & 63) != 0 || h < 1 || n < 1) return VCG_E_UNSUPPORTED;
     if (act != VCG_ACT_NONE && act != VCG_ACT_TANH) return VCG_E_UNSUPPORTED;
+    if ((long)R_CI * h * wd * 4 > 0xFFFFFFE0l) return VCG_E_UNSUPPORTED;          // a wave's 32-channel slab behind one buffer descriptor
     RowChainParams p;
     p.x = x; p.w = w; p.bias = bias; p.y = y;
     p.n = n; p.h = h; p.w_ = wd; p.cout = cout;
     p.strips = wd / 64;
-    p.sh = 128;                                   // shorter segments (more halo recompute) until every CU has an item
-    while (p.sh > 32 && n * p.strips * ceil_div(h, p.sh) < 256) p.sh >>= 1;
-    p.segs = ceil_div(h, p.sh);
+    // segments per column strip: the split that minimises the rows the busiest workgroup marches through (rounds of items per
+    // workgroup x (segment height + 8 recomputed halo rows))
+    {
+        long best = -1;
+        for (int segs = 1; segs <= ceil_div(h, 16); ++segs) {
+            const int sh = ceil_div(h, segs);
+            if (ceil_div(h, sh) != segs) continue;
+            const long items = (long)n * p.strips * segs, rounds = (items + 255) / 256, cost = rounds * (sh + 8);
+            if (best < 0 || cost < best) { best = cost; p.sh = sh; p.segs = segs; }
+        }
+    }
     p.total = n * p.strips * p.segs;
     p.ws_t = ws_t; p.ws_m = ws_m; p.ws_k = ws_k;
     p.act = act;
