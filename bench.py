@@ -181,15 +181,29 @@ def run_c5(args):
         inf.forward(x)
     torch.cuda.synchronize()
     inf._conv = orig
-    ms = [a.elapsed_time(b) for a, b, _ in evs]
-    mean_ms = sum(ms) / len(ms)
     tensor_bytes = B * h * w * 64 * 2
-    nres = sum(1 for _, _, r in evs if r)
-    alg_bytes = (2 * len(evs) + nres) / len(evs) * tensor_bytes + 9 * 64 * 64 * 2        # in + out (+ residual) + weights
-    ach = alg_bytes / (mean_ms * 1e-3) / 1e9
+    wbytes = 9 * 64 * 64 * 2
     flop = 2.0 * 64 * 64 * 9 * h * w * B
-    kname = "conv3x3_c64_bf16_v2_kernel"        # the launches without a residual input; those with one run conv3x3_c64_bf16_kernel (v1)
-    traffic, rec = pmc_traffic(kname, "n%d_%dx%d" % (B, h, w))
+    shape_key = "n%d_%dx%d" % (B, h, w)
+
+    def line(kname, with_res):
+        ms = [a.elapsed_time(b) for a, b, r in evs if r == with_res]
+        if not ms:
+            return None
+        mean_ms = sum(ms) / len(ms)
+        alg_bytes = (3 if with_res else 2) * tensor_bytes + wbytes        # in + out (+ residual) + weights
+        ach = alg_bytes / (mean_ms * 1e-3) / 1e9
+        traffic, rec = pmc_traffic(kname, shape_key)
+        return {"kernel": kname, "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBS, 4),
+                "traffic": traffic, "traffic_source": rec and rec.get("source"), "launches_timed": len(ms), "mean_launch_ms": round(mean_ms, 4),
+                "bytes_per_launch": alg_bytes, "mfma_tflops": round(flop / (mean_ms * 1e-3) / 1e12, 1),
+                "mfma_frac": round(flop / (mean_ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4)}
+    roof = line("conv3x3_c64_bf16_v2_kernel", False)            # the launches without a residual input (conv_pre of every block)
+    roof.update({"bound": "hbm", "bound_note": "priced against HBM (the nearer ceiling) with mfma_frac beside it; the counters show neither saturated "
+                                               "(DESIGN.md section 8): issue / latency inside the tile pipeline at a power-limited clock",
+                 "kernel": roof["kernel"] + " (64->64 3x3 trunk convolution, bf16 NHWC, folded BN + PReLU epilogue)",
+                 "how": "HIP events around the eager launches of 3 passes run right after the timed graph replays",
+                 "residual_variant": line("conv3x3_c64_bf16_kernel", True)})  # conv_post + Add: the v1 kernel, 1.5x the bytes
     out = {
         "metric": "upscaled frames/s (inference, generator only) at %s" % ("256->512" if (h, w) == (256, 256) else "%dx%d->%dx%d" % (h, w, 2 * h, 2 * w)),
         "value": round(B * args.steps / dt, 1), "unit": "frames/s",
@@ -198,12 +212,7 @@ def run_c5(args):
         "config": {"workload": "C5: make_upscaler_orig((%d,%d,3),k=3,x2,res=%d).predict, BN folded, bf16 NHWC activations, fp32 accumulate, "
                                "batch %d, one hipGraph replay per batch" % (2 * h, 2 * w, args.res_blocks, B), "global_batch": B,
                    "frame": "%dx%d->%dx%d" % (h, w, 2 * h, 2 * w), "parallelism": "dp1", "launch": "eager" if args.no_graph else "hipGraph replay"},
-        "roofline": {"bound": "hbm", "kernel": kname + " (64->64 3x3 trunk convolution, bf16 NHWC)", "achieved": round(ach, 1),
-                     "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": traffic,
-                     "traffic_source": rec and rec.get("source"),
-                     "launches_timed": len(evs), "mean_launch_ms": round(mean_ms, 4), "bytes_per_launch": alg_bytes,
-                     "mfma_tflops": round(flop / (mean_ms * 1e-3) / 1e12, 1), "mfma_frac": round(flop / (mean_ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4),
-                     "how": "HIP events around the eager launches of 3 passes run right after the timed graph replays"},
+        "roofline": roof,
     }
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline_c5(args, h, w)
@@ -232,6 +241,9 @@ def main():
                     help="partial mixed precision (generator only); superseded by --dtype bf16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying one hipGraph per step")
+    ap.add_argument("--fused-step", action="store_true",
+                    help="secondary line, never the headline: the documented fast path without the reference's separate predict-mode "
+                         "generator pass (train_gan3.py:346) -- the critic trains on the fakes of the generator's one training-mode forward")
     ap.add_argument("--cpu-sample-batch", type=int, default=2)
     args = ap.parse_args()
     if args.config == "c5":
@@ -277,7 +289,8 @@ def main():
     content = "mse" if args.content == "mse" else PM.VGG_MSE_LOSS((2 * h, 2 * w, 3), 0.1, vgg19="random").loss
     fac = (lambda: PM.WassersteinLosses()) if args.gan_losses == "wass" else (lambda: PM.RelativisticLosses(loss_activation="log-sigm"))
     gen_train, disc_train, gan_train = PM.make_and_compile_gan2(
-        G, D, (h, w, 3), (2 * h, 2 * w, 3), content, 1.0, fac, 1e-5, optimizer=PM.Adam(), process_group=group)
+        G, D, (h, w, 3), (2 * h, 2 * w, 3), content, 1.0, fac, 1e-5, optimizer=PM.Adam(), process_group=group,
+        fused_step=args.fused_step)
     trainer = gan_train.trainer
     rt = E.Runtime.get()
 
@@ -313,30 +326,55 @@ def main():
         step(lr, hr)
     bf16_trunk = trunk_dtype != "fp32" and k == 3
     dom_tags = ("trunk_conv", "trunk_conv_dgrad")
+    res_tags = ("trunk_conv_res", "trunk_conv_dgrad_res")     # bf16: the launches with a residual input run the v1 kernel
     if not use_graph:
-        rt.prof = KernelProf(dom_tags)
+        rt.prof = KernelProf(dom_tags + res_tags)
+    if group is not None:
+        trainer.coll_prof = {}                  # HIP events around every collective (compute stream: the exposed time)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     sync()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    marks[0].record()
+    for i in range(args.steps):
         losses = step(lr, hr)
+        marks[i + 1].record()                   # per-step device time of this rank, read after the timed region (no sync inside it)
     sync()
     dt = time.perf_counter() - t0
     prof, rt.prof = rt.prof, None
+    coll_prof, trainer.coll_prof = trainer.coll_prof, None
+    step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
     roof_note = "HIP events around every launch of the kernel inside the timed region"
     if use_graph:
         # kernels inside a graph replay cannot be bracketed one by one: time the same kernel launches with HIP
         # events in eager steps of the same workload right after the timed region
-        rt.prof = prof = KernelProf(dom_tags)
+        rt.prof = prof = KernelProf(dom_tags + res_tags)
         for _ in range(3):
             trainer.train_step(lr, hr)
         torch.cuda.synchronize()
         rt.prof = None
-        roof_note = ("the timed region replays one hipGraph per step, which cannot be bracketed per kernel; these are HIP-event "
-                     "timings of the same launches in 3 eager steps of the same workload run right after it")
+        roof_note = ("the timed region replays the recorded hipGraph(s) of the step, which cannot be bracketed per kernel; these are HIP-event "
+                     "timings of the same launches in 3 eager steps of the same workload run right after it (a different clock / "
+                     "thermal state than the replays: the rocprofv3 --stats average of the replayed launches is under profiles/)")
 
     dt_t = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearsal else rt.device)
+    dp_info = None
     if group is not None:
         dist.all_reduce(dt_t, op=dist.ReduceOp.MAX, group=group)
+        # what makes an N > 1 record explain itself: every rank's step times and the time its compute stream waited at each collective
+        mine = {"rank": rank, "wall_s": round(dt, 4), "step_ms_min": round(step_ms[0], 3), "step_ms_median": round(step_ms[len(step_ms) // 2], 3),
+                "step_ms_max": round(step_ms[-1], 3),
+                "collectives_ms": {name: round(sum(a.elapsed_time(b) for a, b in ev) / max(len(ev), 1), 4) for name, ev in sorted((coll_prof or {}).items())}}
+        allr = [None] * world
+        dist.all_gather_object(allr, mine, group=group)
+        names = sorted(allr[0]["collectives_ms"])
+        dp_info = {"rccl_ranks": dist.get_world_size(group), "backend": dist.get_backend(group),
+                   "bucket_bytes": {"d_bucket": int(D.ps.n_trainable) * 4, "g_bucket": int(G.ps.n_trainable) * 4,
+                                    "means": 8 if trainer.relativistic else 0},
+                   "collective_ms_mean_over_ranks": {nm: round(sum(r["collectives_ms"][nm] for r in allr) / world, 4) for nm in names},
+                   "collective_ms_max_over_ranks": {nm: round(max(r["collectives_ms"][nm] for r in allr), 4) for nm in names},
+                   "collectives_note": "HIP events on the compute stream around each collective = the time the step is exposed to it; the critic's bucket "
+                                       "is issued (d_bucket_issue) before the generator's training-mode forward and waited for after it (d_bucket_wait)",
+                   "per_rank": allr}
     dt = float(dt_t.item())
     frames = args.batch * world * args.steps
 
@@ -348,14 +386,25 @@ def main():
     if mean_ms:
         tfl = flop_per_launch / (mean_ms * 1e-3) / 1e12
         if bf16_trunk:
-            # bf16 NHWC: 142 KB of traffic per 16x32-pixel tile against 9.2k MFMA cycles -- at the ridge; priced against HBM (and see DESIGN.md section 8:
-            # the dense bf16 MFMA peak is not reachable on non-zero operands, the chip throttles to 1.5-1.75 PFLOP/s)
-            kname = "conv3x3_c64_bf16_v2_kernel"        # the launches without a residual input; those with one run conv3x3_c64_bf16_kernel (v1)
+            # bf16 NHWC: 142 KB of traffic per 16x32-pixel tile against 9.2k MFMA cycles -- near the ridge.  Both ratios are printed (HBM
+            # against the 8 TB/s spec, MFMA against the 2.5 PFLOP/s dense spec); `bound` names what the PMC passes show for this kernel
+            # (DESIGN.md section 8): neither pipe is saturated -- issue / latency inside the tile pipeline, at a power-limited clock.
+            kname = "conv3x3_c64_bf16_v2_kernel"        # the launches without a residual input; those with one run conv3x3_c64_bf16_kernel (v1), below
             alg_bytes = 2 * args.batch * h * w * 64 * 2 + 9 * 64 * 64 * 2
             ach = alg_bytes / (mean_ms * 1e-3) / 1e9
-            roof = {"bound": "hbm", "kernel": kname + " (64->64 3x3 trunk conv on bf16 NHWC, forward + dgrad)", "achieved": round(ach, 1),
+            roof = {"bound": "hbm", "bound_note": "priced against HBM (the nearer of the two ceilings: frac) with mfma_frac beside it; the counters "
+                                                  "(profiles/, MfmaUtil and achieved GB/s) show neither saturated: the limiter is issue/latency in the tile pipeline",
+                    "kernel": kname + " (64->64 3x3 trunk conv on bf16 NHWC without a residual input, forward + dgrad)", "achieved": round(ach, 1),
                     "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBS, 4), "bytes_per_launch": alg_bytes,
                     "mfma_tflops": round(tfl, 1), "mfma_frac": round(tfl / PEAK_BF16_MFMA_TFLOPS, 4)}
+            r_ms, r_n = prof.mean_ms(res_tags)
+            if r_ms:
+                r_bytes = 3 * args.batch * h * w * 64 * 2 + 9 * 64 * 64 * 2          # input + residual + output + weights
+                r_traffic, _ = pmc_traffic("conv3x3_c64_bf16_kernel", shape_key)
+                roof["residual_variant"] = {"kernel": "conv3x3_c64_bf16_kernel (the same convolution with a residual / skip-gradient input)",
+                                            "launches_timed": r_n, "mean_launch_ms": round(r_ms, 4), "bytes_per_launch": r_bytes,
+                                            "achieved": round(r_bytes / (r_ms * 1e-3) / 1e9, 1), "frac": round(r_bytes / (r_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+                                            "mfma_tflops": round(flop_per_launch / (r_ms * 1e-3) / 1e12, 1), "traffic": r_traffic}
         else:
             kname = "conv_fwd_kernel<%d, %d, 1, 8, %d>" % (k, k, 2 if k == 3 else 1)
             roof = {"bound": "mfma", "kernel": kname + " (64->64 %dx%d trunk conv, forward + dgrad)" % (k, k),
@@ -376,16 +425,22 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": dts, "data": "synthetic",
             "config": {"workload": wl + ": make_upscaler_orig((%d,%d,3),k=%d,x2,res=%d) + %s%s, batch %d/GPU, "
-                                   "gan2 wiring, %s + %s, faithful 3-call step incl. predict pass"
+                                   "gan2 wiring, %s + %s, %s"
                                    % (2 * h, 2 * w, k, args.res_blocks, "PatchGAN-70" if args.disc == "patchgan" else "simple_512",
                                       "" if args.disc_activation == "none" else "(%s)" % args.disc_activation, args.batch,
                                       "Wasserstein" if args.gan_losses == "wass" else "Relativistic(log-sigm)",
-                                      "pixel-MSE" if args.content == "mse" else "VGG_MSE_LOSS(0.1), random VGG19 weights"),
+                                      "pixel-MSE" if args.content == "mse" else "VGG_MSE_LOSS(0.1), random VGG19 weights",
+                                      "FUSED step (extension, not the headline): no separate predict pass, 3 G + 9 D forward-equivalents" if args.fused_step
+                                      else "faithful 3-call step incl. predict pass"),
                        "global_batch": args.batch * world, "frame": "%dx%d->%dx%d" % (h, w, 2 * h, 2 * w),
                        "parallelism": "dp%d" % world, "launch": ("hipGraph replay" if world == 1 else "%d hipGraphs per step around the RCCL all-reduces" % len(trainer._graph)) if use_graph else "eager"},
             "last_losses": [round(float(v), 6) for v in losses],
             "roofline": roof,
         }
+        if dp_info is not None:
+            out["data_parallel"] = dp_info
+            if rehearsal:
+                out["rehearsal"] = "VCG_BENCH_REHEARSAL=1: all ranks on ONE GPU, gloo through the host instead of RCCL -- exercises the launcher / multi-graph / reduction logic; its numbers are NOT a scaling measurement"
         if world == 1 and not args.no_cpu_baseline and args.content == "mse" and w == h:
             out["cpu_baseline"] = cpu_baseline(args, h, w)
         print(json.dumps(out), flush=True)

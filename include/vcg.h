@@ -343,6 +343,17 @@ int vcg_norm_act_bwd_bf16(const void* x, const void* dy, int n, int c, int hw, i
 
 /* weight (and bias) gradient of the bf16 3x3 stride-1 'same' 64->64 convolution: x, dy bf16 NHWC; dw fp32 in Keras' (3,3,in,out)
  * layout (it accumulates into the fp32 master-weight gradient like vcg_conv2d_wgrad), dbias [64] fp32 or NULL. */
+/* ---- one-output-channel Conv2D on bf16 NHWC: the 70x70 PatchGAN's last layer, Conv2D(1, 4) on 512 channels (north_star extension, SURVEY.md
+ *      section 8 row a11; follows the reference's critic factories, upscaling/upscaler/model.py:836-896).  x / dx: bf16 [n][h][w][cin]
+ *      (cin a multiple of 8, <= 512), y / dy: fp32 [n][1][oh][ow], w_hwio: the Keras kernel (kh,kw,cin,1) in fp32; 3x3 / 4x4, stride 1,
+ *      any zero padding.  VCG_E_UNSUPPORTED otherwise (the caller then uses vcg_conv2d_* on fp32 copies). ------------------------------ */
+int vcg_conv2d_cout1_nhwc_bf16_fwd(const vcg_conv_desc* d, const void* x, const float* w_hwio, const float* bias, float* y, vcg_stream_t stream);
+int vcg_conv2d_cout1_nhwc_bf16_dgrad(const vcg_conv_desc* d, const float* dy, const float* w_hwio, void* dx, vcg_stream_t stream);
+size_t vcg_conv2d_cout1_nhwc_bf16_wgrad_workspace_bytes(const vcg_conv_desc* d);
+/* dw_hwio and dbias (may be NULL) are overwritten; deterministic (fixed-order sum of per-workgroup records) */
+int vcg_conv2d_cout1_nhwc_bf16_wgrad(const vcg_conv_desc* d, const void* x, const float* dy, float* dw_hwio, float* dbias, void* ws, size_t ws_bytes,
+                                     vcg_stream_t stream);
+
 size_t vcg_conv2d_bf16_wgrad_workspace_bytes(const vcg_conv_desc* d);
 int vcg_conv2d_bf16_wgrad(const vcg_conv_desc* d, const void* x, const void* dy, float* dw_hwio, float* dbias, void* ws, size_t ws_bytes,
                           hipStream_t stream);

@@ -176,3 +176,14 @@ class GanOracle:
         loss_disc = self.disc_train_on_batch(hr, fake)
         loss_gan, loss_gan_gen, loss_gan_disc = self.gan_train_on_batch(lr, hr)
         return loss_disc, loss_gan, loss_gan_gen, loss_gan_disc
+
+    def train_step_fused(self, lr, hr):
+        """The documented deviation `fused=True` of the build ("three-graph semantics"; NOT in the reference): the
+        loop body without its separate learning-phase-0 generator pass (train_gan3.py:346).  The critic is trained on the fakes of
+        the generator's training-mode forward (batch statistics), and the generator step (model.py:1103-1123) re-uses that forward --
+        the generator's weights do not change in between, so re-evaluating it here gives the same tensors."""
+        with torch.no_grad():
+            fake, _ = self.g_forward(self.g_w, lr, True)
+        loss_disc = self.disc_train_on_batch(hr, fake)
+        loss_gan, loss_gan_gen, loss_gan_disc = self.gan_train_on_batch(lr, hr)
+        return loss_disc, loss_gan, loss_gan_gen, loss_gan_disc

@@ -1,5 +1,5 @@
 """RCCL smoke of the data-parallel step on ONE GPU: a 1-rank "nccl" process group drives exactly the code path the
-N-GPU bench takes (bucket all-reduces between the three hipGraphs, loss scalars reduced at read-out); with one rank
+N-GPU bench takes (bucket all-reduces between the four hipGraphs, loss scalars reduced at read-out); with one rank
 the result must equal the single-process step bit for bit.  python scripts/dp_nccl_smoke.py"""
 import os
 import sys
@@ -29,7 +29,8 @@ def run(group, graph):
     steps = [(E.to_device_nchw(rt, rng.randint(0, 256, (4, 32, 32, 3)) / 127.5 - 1),
               E.to_device_nchw(rt, rng.randint(0, 256, (4, 64, 64, 3)) / 127.5 - 1)) for _ in range(3)]
     if graph:
-        tr.capture_train_step(*steps[0])
+        run.ngraphs = tr.capture_train_step(*steps[0])
+        run.ngraphs = run.ngraphs if isinstance(run.ngraphs, list) else [run.ngraphs]
         for a, b in steps[1:]:
             out.append(tr.train_step_graph(a, b))
     else:
@@ -54,7 +55,7 @@ def main():
         got = run(group, graph)
         same = torch.equal(got[1], ref[1]) and torch.equal(got[2], ref[2])
         print("nccl world=1 %s: losses %s  weights identical to the single-process step: %s"
-              % ("3 hipGraphs + eager all-reduce" if graph else "eager", ["%.6g" % v for v in got[0]], same), flush=True)
+              % ("%d hipGraphs + eager all-reduces" % len(getattr(run, "ngraphs", [0] * 4)) if graph else "eager", ["%.6g" % v for v in got[0]], same), flush=True)
         assert same and got[0] == ref[0]
     dist.barrier()
     dist.destroy_process_group()

@@ -677,6 +677,51 @@ def test_generic_conv_bf16_fwd_dgrad_wgrad(rt, cin, cout, k, stride, padding, n,
     assert torch.equal(g1, ps.grad("c/kernel"))
 
 
+@pytest.mark.parametrize("cin,k,padding,n,h,w", [
+    (512, 4, 1, 2, 15, 15),          # the PatchGAN head at a 64x64... input: 15 -> 14
+    (512, 4, 1, 3, 63, 63),          # its size at C2 / C3 (512x512 frames): 63 -> 62, several segments per row, ragged last segment
+    (512, 4, 1, 1, 20, 37),          # not square
+    (256, 4, 1, 2, 9, 11),           # fewer than 512 channels: idle lanes
+    (64, 3, "same", 2, 17, 16),      # 3x3 'same'
+    (512, 3, 1, 1, 8, 33),
+])
+def test_cout1_conv_bf16_fwd_dgrad_wgrad(rt, cin, k, padding, n, h, w):
+    """ConvCout1Bf16 (vcg_conv2d_cout1_nhwc_bf16_*: the PatchGAN head on bf16 NHWC activations, fp32 weights) against the fp64 oracle on
+    the same bf16-rounded activations: fp32 outputs / weight gradients to 1e-5, the bf16-stored data gradient to 2^-8."""
+    from oracle import keras_ops as K
+    from upscaler import _engine as E
+    layer = E.ConvCout1Bf16("c", cin, 1, k, 1, padding)
+    ps = E.ParamStore()
+    layer.declare(ps)
+    ps.materialize(rt)
+    layer.bind(rt, ps)
+    g = torch.Generator().manual_seed(cin + k * 7 + h)
+    wk = torch.randn(k, k, cin, 1, generator=g) * (2.0 / (k * k * cin)) ** 0.5
+    bk = torch.randn(1, generator=g) * 0.1
+    ps.set_weights({"c/kernel": wk.numpy(), "c/bias": bk.numpy()})
+    x = torch.randn(n, cin, h, w, generator=g)
+    xr = _bf16_round(x).requires_grad_(True)
+    wr = wk.double().requires_grad_(True)
+    br = bk.double().requires_grad_(True)
+    yr = K.conv2d(xr, wr, br, 1, padding)
+    dy = torch.randn(*yr.shape, generator=g)
+    (yr * dy.double()).sum().backward()
+    xd = _to_nhwc_bf16(rt, x.to(rt.device))
+    y, ctx = layer.forward(xd)
+    assert tuple(y.shape) == tuple(yr.shape)
+    dx = layer.backward(ctx, dy.to(rt.device).contiguous(), True, True, 0)
+    e_y = rel_err(y, yr)
+    e_dx = rel_err(_to_nchw_f32(rt, dx), xr.grad)
+    e_dw = rel_err(ps.grad("c/kernel"), wr.grad)
+    e_db = rel_err(ps.grad("c/bias"), br.grad)
+    report("cout1 bf16 conv %d->1 k%d pad=%s n=%d %dx%d: fwd=%.2e dgrad=%.2e wgrad=%.2e dbias=%.2e" % (cin, k, padding, n, h, w, e_y, e_dx, e_dw, e_db))
+    assert e_y < 1e-5 and e_dw < 1e-5 and e_db < 1e-5
+    assert e_dx < TOL_BF16
+    g1 = ps.grad("c/kernel").clone()
+    layer.backward(ctx, dy.to(rt.device).contiguous(), False, True, 0)
+    assert torch.equal(g1, ps.grad("c/kernel"))
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # bf16 discriminators and the all-bf16 train step (BASELINE.json configs C3 / C4)
 # ---------------------------------------------------------------------------------------------------------------

@@ -1,7 +1,7 @@
 """Data parallelism of the PRODUCT path on the GPU: two ranks (gloo, sharing the one GPU of the test box; on a
 node it is one RCCL rank per GPU, same code) train on the two halves of a batch; their weights after three
 steps must equal the single-process run on the whole batch -- instance-norm models, so that per-replica
-statistics do not change the maths.  Run eagerly and as the three-graph replay."""
+statistics do not change the maths.  Run eagerly and as the multi-graph replay (four graphs around the all-reduces)."""
 import os
 import socket
 import subprocess
@@ -47,10 +47,11 @@ def _run(world, mode, out):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["eager", "graph", "graph-bf16", "graph-rel"])
+@pytest.mark.parametrize("mode", ["eager", "graph", "graph-bf16", "graph-rel", "graph-fused"])
 def test_two_rank_step_equals_whole_batch_step(tmp_path, mode):
     """fp32 eager / recorded; the all-bf16 models (config C3's arithmetic); the relativistic losses, whose non-linearity needs
-    the GLOBAL means (a 2-float all-reduce inside the step: five graphs per step)"""
+    the GLOBAL means (a 2-float all-reduce inside the step: six graphs per step); the fused step (no predict pass).  In every
+    mode the critic's bucket is issued before the generator's training-mode forward and waited for after it."""
     ref_mode = "eager" + ("-" + mode.split("-")[1] if "-" in mode else "")
     one = _run(1, ref_mode, str(tmp_path / "one.npz"))
     two = _run(2, mode, str(tmp_path / "two.npz"))
@@ -72,7 +73,7 @@ def test_two_rank_step_equals_whole_batch_step(tmp_path, mode):
 
 @pytest.mark.gpu
 def test_rccl_one_rank_group_is_bit_identical():
-    """scripts/dp_nccl_smoke.py: the DP code path over a real (1-rank) RCCL communicator -- eager and as the three
+    """scripts/dp_nccl_smoke.py: the DP code path over a real (1-rank) RCCL communicator -- eager and as the four
     hipGraphs around the all-reduces -- reproduces the single-process step bit for bit"""
     script = os.path.join(os.path.dirname(HERE), "scripts", "dp_nccl_smoke.py")
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")

@@ -249,3 +249,26 @@ def test_c_abi_argument_validation_without_a_gpu():
     # and the Python shim turns them into exceptions
     with pytest.raises((ValueError, RuntimeError)):
         L.check(E_SHAPE, "test")
+
+
+def test_conv2d_bf16_constructor_only_accepts_trainable_shapes():
+    """a Conv2DBf16 is built only for shapes its weight-gradient kernel serves (3x3 / 4x4, stride 1 / 2, channel
+    multiples of 64) -- a 5x5 or 32-channel layer must fail at construction, not at the first training step"""
+    from upscaler import _engine as E
+    E.Conv2DBf16("ok", 64, 128, 4, 2, 1)
+    for bad in ((32, 64, 3, 1), (64, 96, 3, 1), (64, 64, 5, 1), (64, 64, 3, 3)):
+        with pytest.raises(NotImplementedError):
+            E.Conv2DBf16("bad", bad[0], bad[1], bad[2], bad[3], "same")
+
+
+def test_fused_step_is_opt_in_and_oracle_restates_it():
+    """the faithful three-call step is the default everywhere; `fused_step` is an extension keyword behind the reference's arguments"""
+    import inspect
+    from oracle import train as OT
+    from upscaler import model as PM
+    for f in (PM.make_and_compile_gan, PM.make_and_compile_gan2):
+        ps = inspect.signature(f).parameters
+        assert ps["fused_step"].default is False and list(ps)[-1] == "fused_step"
+    assert hasattr(OT.GanOracle, "train_step_fused")
+    src = inspect.getsource(PM.GanTrainer.__init__)
+    assert "self.fused = False" in src

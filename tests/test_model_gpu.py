@@ -359,6 +359,54 @@ def test_graph_replay_matches_eager(rt, losses, disc, d_act):
             assert np.array_equal(we[k], wg[k]), k
 
 
+@pytest.mark.parametrize("losses,disc,d_act", [("wass", "patch", "none"), ("rel", "simple", "bi-log")])
+def test_fused_step_matches_oracle_and_replays(rt, losses, disc, d_act):
+    """GanTrainer.fused (extension; the faithful three-call step stays the default): no separate predict-mode generator pass
+    (train_gan3.py:346) -- the critic trains on the fakes of the generator's ONE training-mode forward, which the generator step
+    re-uses.  Two iterations against the oracle's restatement of the same deviation (GanOracle.train_step_fused), then the
+    recorded hipGraph of the fused step against the eager one, bit for bit."""
+    from upscaler import _engine as E
+    bs = 4
+    G, D, df, models, opt, mk = _build_pair(rt, "gan2", losses, disc, 3, ADAM_V0, d_act=d_act)
+    tr = models[2].trainer
+    orc = mk(torch.float64)
+    for it in range(2):
+        lr, hr = _frames(50 + it, bs, 64, 64), _frames(60 + it, bs, 128, 128)
+        got = tr.train_step(E.to_device_nchw(rt, lr), E.to_device_nchw(rt, hr), fused=True)
+        ref = orc.train_step_fused(torch.tensor(lr, dtype=torch.float64), torch.tensor(hr, dtype=torch.float64))
+        scale = max(abs(v) for v in ref) + 1e-6
+        for name, a, b in zip(("disc", "gan", "content", "adv"), got, ref):
+            report("fused step %s/%s it=%d loss_%s got=%.6g ref=%.6g err=%.1e" % (losses, disc, it, name, a, b, abs(a - b) / scale))
+            assert abs(a - b) / scale < TOL, (name, a, b)
+    assert tr.fused and opt.iterations == orc.opt.iterations == 4
+    lr0 = _frames(50, bs, 64, 64)
+    e_g = rel_err(torch.tensor(models[0].predict(lr0)), orc.predict(torch.tensor(lr0, dtype=torch.float64)))
+    report("fused step %s/%s after: G.predict err=%.2e" % (losses, disc, e_g))
+    assert e_g < TOL
+    # the fused step differs from the faithful one (its fakes come from batch statistics)
+    frames = [(_frames(70 + i, bs, 64, 64), _frames(80 + i, bs, 128, 128)) for i in range(3)]
+
+    def run(graph, fused):
+        G, D, df, models, opt, mk = _build_pair(rt, "gan2", losses, disc, 3, 0.0, d_act=d_act)
+        tr = models[2].trainer
+        dev = [(E.to_device_nchw(rt, a), E.to_device_nchw(rt, b)) for a, b in frames]
+        if graph:
+            tr.capture_train_step(*dev[0], fused=fused)
+            out = [tr.train_step_graph(a, b) for a, b in dev[1:]]
+        else:
+            tr._t_dev = torch.tensor([opt.iterations, 0], dtype=torch.int32, device=rt.device)
+            tr.train_step(*dev[0], fused=fused)
+            out = [tr.train_step(a, b) for a, b in dev[1:]]
+        return out, G.get_weights_dict()
+    oe, ge = run(False, True)
+    og, gg = run(True, True)
+    of, _ = run(False, False)
+    assert oe == og, (oe, og)
+    for k in ge:
+        assert np.array_equal(ge[k], gg[k]), k
+    assert oe != of             # a different step, not an alias of the faithful one
+
+
 def test_c4_frame_size_train_step_runs(rt):
     """BASELINE.json config C4's frame size (540x960 -> 1080x1920, not a multiple of any tile edge) through one whole
     train step at batch 1: finite losses, and the generator's prediction matches the oracle on a crop-free 1080p frame

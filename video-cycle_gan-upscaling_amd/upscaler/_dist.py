@@ -40,6 +40,23 @@ def allreduce_sum(flat, group):
     return flat
 
 
+class _Done:
+    def wait(self):
+        return None
+
+
+def allreduce_sum_start(flat, group):
+    """allreduce_sum without waiting: returns a handle whose wait() makes the current stream wait for the result.  With RCCL the
+    collective runs on the communicator's own stream behind the work queued so far, so kernels launched between start and wait()
+    overlap it -- they must not touch `flat`.  (gloo on device buffers, the test rig, completes at once through the host.)"""
+    if group is None or flat.numel() == 0:
+        return _Done()
+    if flat.is_cuda and dist.get_backend(group) == "gloo":
+        allreduce_sum(flat, group)
+        return _Done()
+    return dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=True)
+
+
 def world_size(group):
     return 1 if group is None else dist.get_world_size(group)
 

@@ -291,7 +291,7 @@ class Conv2D(Layer):
                 s = self.stride
                 dyd = rt.empty(n, self.cout, (d.oh - 1) * s + 1, (d.ow - 1) * s + 1)
                 L.check(rt.lib.vcg_dilate2d(dy.data_ptr(), dyd.data_ptr(), n * self.cout, d.oh, d.ow, s, rt.stream), "vcg_dilate2d")
-                dd = L.ConvDesc(n, self.cin, d.h, d.w, self.cout, dyd.shape[2], dyd.shape[3], self.k, self.k, 1, d.pad_top, d.pad_left)
+                dd = L.ConvDesc(n, self.cin, d.h, d.w, self.cout, dyd.shape[2], dyd.shape[3], self.kh, self.kw, 1, d.pad_top, d.pad_left)
             with Timed(rt, tag and tag + "_dgrad"):
                 L.check(rt.lib.vcg_conv2d_dgrad(ctypes.byref(dd), dyd.data_ptr(), self.ps[self.name + "/kernel"].data_ptr(),
                                                 self._wt().data_ptr(), dx.data_ptr(), _ptr(dx_residual), rt.stream),
@@ -668,7 +668,7 @@ class Conv3x3Bf16(Layer):
         y = torch.empty(n, h, wd, 64, dtype=torch.bfloat16, device=rt.device)
         d = L.ConvDesc(n, 64, h, wd, 64, h, wd, 3, 3, 1, 1, 1)
         ep = L.EpilogueBf16(scale.data_ptr(), shift.data_ptr(), norm.act, float(norm.alpha), norm._alpha_ptr(), _ptr(residual), None, L.STATS_NONE)
-        with Timed(rt, tag):
+        with Timed(rt, tag and residual is not None and tag + "_res" or tag):
             L.check(rt.lib.vcg_conv2d_bf16_fwd(ctypes.byref(d), x.data_ptr(), wf.data_ptr(), y.data_ptr(), ctypes.byref(ep), rt.stream),
                     "vcg_conv2d_bf16_fwd[%s]" % self.name)
         return y
@@ -704,22 +704,24 @@ class Conv3x3Bf16(Layer):
         if not need_dx:
             return None
         _, wdg = self._packed()
-        with Timed(rt, tag and tag + "_dgrad"):
+        with Timed(rt, tag and tag + ("_dgrad_res" if dx_residual is not None else "_dgrad")):
             dx, _ = self._run(dy, wdg, None, dx_residual)
         return dx
 
 
 class Conv2DBf16(Conv2D):
-    """keras.layers.Conv2D on bf16 NHWC activations, any of the discriminators' shapes (3x3 / 4x4 / 5x5, stride 1-3, channel
-    counts that are multiples of 32): forward and data gradient on vcg_conv2d_nhwc_bf16_* (weights re-laid out as MFMA operand
+    """keras.layers.Conv2D on bf16 NHWC activations, the discriminators' shapes (3x3 / 4x4, stride 1 / 2, channel counts that
+    are multiples of 64 -- what the bf16 weight gradient serves): forward and data gradient on vcg_conv2d_nhwc_bf16_* (weights re-laid out as MFMA operand
     fragments after every optimizer step), weight gradient on vcg_conv2d_nhwc_bf16_wgrad; fp32 master weights, gradients and
     bias.  Same parameter names / layouts as Conv2D: a bf16 model exchanges weights with the fp32 one and with the reference."""
 
     def __init__(self, name, cin, cout, k, stride=1, padding="same", act=L.ACT_NONE, alpha=0.0):
         if act != L.ACT_NONE:
             raise NotImplementedError("Conv2DBf16 carries no fused activation (the layers it serves are followed by a normalisation)")
-        if cin % 32 or cout % 32:
-            raise NotImplementedError("Conv2DBf16 needs channel counts that are multiples of 32")
+        if cin % 64 or cout % 64 or k not in (3, 4) or stride not in (1, 2):
+            # vcg_conv2d_nhwc_bf16_fwd/_dgrad take more (5x5, stride 3, multiples of 32); the bf16 weight gradient
+            # (bf16_gwgrad.hip: gw_plan) serves 3x3 / 4x4, stride 1 / 2, channel multiples of 64 -- a layer is built only if it can train
+            raise NotImplementedError("Conv2DBf16 serves 3x3 / 4x4 kernels, stride 1 / 2, channel counts that are multiples of 64")
         super().__init__(name, cin, cout, k, stride, padding, act, alpha)
         self._wf = self._wd = None
         self._pvalid = False
@@ -787,6 +789,46 @@ class Conv2DBf16(Conv2D):
         with Timed(rt, tag and tag + "_dgrad"):
             L.check(rt.lib.vcg_conv2d_nhwc_bf16_dgrad(ctypes.byref(d), dy.data_ptr(), wd.data_ptr(), None, 0.0, dx.data_ptr(), rt.stream),
                     "vcg_conv2d_nhwc_bf16_dgrad[%s]" % self.name)
+        return dx
+
+
+class ConvCout1Bf16(Conv2D):
+    """Conv2D(1, k) on bf16 NHWC activations -- the 70x70 PatchGAN's last layer (512 -> 1, 4x4, zero padding 1) in the bf16 configs:
+    forward, data gradient and weight gradient on vcg_conv2d_cout1_nhwc_bf16_* straight from / to the bf16 NHWC tensor (fp32
+    weights, fp32 accumulation, fp32 [n,1,oh,ow] output).  Same parameter names / layouts as Conv2D."""
+
+    def __init__(self, name, cin, cout, k, stride=1, padding="same", act=L.ACT_NONE, alpha=0.0):
+        if cout != 1 or stride != 1 or act != L.ACT_NONE or k not in (3, 4) or cin % 8 or cin > 512:
+            raise NotImplementedError("ConvCout1Bf16 serves Conv2D(1, 3|4, stride 1) on up to 512 channels (multiples of 8), no activation")
+        super().__init__(name, cin, cout, k, stride, padding, act, alpha)
+
+    def forward(self, x, residual=None, tag=None):
+        rt = self.rt
+        n, h, w, _ = x.shape
+        d = self.desc(n, h, w)
+        y = rt.empty(n, 1, d.oh, d.ow)
+        with Timed(rt, tag):
+            L.check(rt.lib.vcg_conv2d_cout1_nhwc_bf16_fwd(ctypes.byref(d), x.data_ptr(), self.ps[self.name + "/kernel"].data_ptr(),
+                                                          self.ps[self.name + "/bias"].data_ptr(), y.data_ptr(), rt.stream),
+                    "vcg_conv2d_cout1_nhwc_bf16_fwd[%s]" % self.name)
+        return y, (x, None, d)
+
+    def backward(self, ctx, dy, need_dx=True, param_grads=True, which=0, dx_residual=None, tag=None):
+        rt = self.rt
+        x, _, d = ctx
+        if param_grads:
+            ws, wsn = rt.workspace(rt.lib.vcg_conv2d_cout1_nhwc_bf16_wgrad_workspace_bytes(ctypes.byref(d)))
+            with Timed(rt, tag and tag + "_wgrad"):
+                L.check(rt.lib.vcg_conv2d_cout1_nhwc_bf16_wgrad(ctypes.byref(d), x.data_ptr(), dy.data_ptr(),
+                                                                self.ps.grad(self.name + "/kernel", which).data_ptr(),
+                                                                self.ps.grad(self.name + "/bias", which).data_ptr(), ws, wsn, rt.stream),
+                        "vcg_conv2d_cout1_nhwc_bf16_wgrad[%s]" % self.name)
+        if not need_dx:
+            return None
+        dx = torch.empty_like(x)
+        with Timed(rt, tag and tag + "_dgrad"):
+            L.check(rt.lib.vcg_conv2d_cout1_nhwc_bf16_dgrad(ctypes.byref(d), dy.data_ptr(), self.ps[self.name + "/kernel"].data_ptr(),
+                                                            dx.data_ptr(), rt.stream), "vcg_conv2d_cout1_nhwc_bf16_dgrad[%s]" % self.name)
         return dx
 
 

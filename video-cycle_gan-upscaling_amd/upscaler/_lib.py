@@ -113,6 +113,10 @@ SIGNATURES = {
     "vcg_norm_act_bwd_bf16_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "vcg_norm_act_bwd_bf16": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_int, c_float, _P, c_int, _P, _P, _P, _P, _P,
                                       c_size_t, _P]),
+    "vcg_conv2d_cout1_nhwc_bf16_fwd": (c_int, [_D, _P, _P, _P, _P, _P]),
+    "vcg_conv2d_cout1_nhwc_bf16_dgrad": (c_int, [_D, _P, _P, _P, _P]),
+    "vcg_conv2d_cout1_nhwc_bf16_wgrad_workspace_bytes": (c_size_t, [_D]),
+    "vcg_conv2d_cout1_nhwc_bf16_wgrad": (c_int, [_D, _P, _P, _P, _P, _P, c_size_t, _P]),
     "vcg_conv2d_bf16_wgrad_workspace_bytes": (c_size_t, [_D]),
     "vcg_conv2d_bf16_wgrad": (c_int, [_D, _P, _P, _P, _P, _P, c_size_t, _P]),
     "vcg_conv9x9_to3_bf16_wgrad_workspace_bytes": (c_size_t, [_D]),

@@ -13,6 +13,7 @@ Extensions named by north_star with no reference counterpart (SURVEY.md section 
   make_discriminator_patchgan_70, ``norm='instance'``.
 """
 import math
+import os
 from abc import ABCMeta, abstractmethod
 from collections import OrderedDict
 
@@ -631,11 +632,15 @@ class DiscriminatorStack(Model):
         return d
 
 
+HEAD_BF16 = os.environ.get("VCG_HEAD_BF16", "1") != "0"      # A/B switch (bench scripts): "0" = the fp32 head on layout-converted copies
+
+
 class DiscriminatorPatchGAN(Model):
     """70x70 PatchGAN (north_star extension): C64-C128-C256 (k4 s2),
     C512 (k4 s1), C1 (k4 s1), zero padding 1, LeakyReLU 0.2, instance (default) or batch norm on the
     three middle blocks.  ``dtype='bf16'``: the three middle blocks (99 % of its FLOPs) on bf16 NHWC activations
-    (Conv2DBf16 / NormActBf16); the 3-channel first and the 1-channel last convolution stay fp32."""
+    (Conv2DBf16 / NormActBf16), the 1-channel last convolution reads them as they are (ConvCout1Bf16: fp32 weights and output); the
+    3-channel first convolution is fp32."""
     SPEC = ((64, 2, False), (128, 2, True), (256, 2, True), (512, 1, True), (1, 1, False))
 
     def __init__(self, input_shape, activation, norm, seed, dtype="fp32"):
@@ -654,6 +659,9 @@ class DiscriminatorPatchGAN(Model):
                 bf = dtype == "bf16"
                 cv = self._add((E.Conv2DBf16 if bf else E.Conv2D)(n + "/Conv2d", cin, f, 4, s, 1))
                 na = self._add((E.NormActBf16 if bf else E.NormAct)(n + "/BatchNorm", f, norm, L.ACT_LRELU, 0.2))
+            elif last and dtype == "bf16" and HEAD_BF16:
+                cv = self._add(E.ConvCout1Bf16(n + "/Conv2d", cin, f, 4, s, 1))         # reads / writes the bf16 NHWC tensor directly
+                na = None
             else:
                 cv = self._add(E.Conv2D(n + "/Conv2d", cin, f, 4, s, 1, L.ACT_NONE if last else L.ACT_LRELU, 0.2))
                 na = None
@@ -675,7 +683,7 @@ class DiscriminatorPatchGAN(Model):
         for i, (cv, na) in enumerate(self.convs):
             if bf and i == 1:
                 h = E.to_bf16_nhwc(rt, h)
-            if bf and i == last:
+            if bf and i == last and not isinstance(cv, E.ConvCout1Bf16):
                 h = E.from_bf16_nhwc(rt, h)
             if bf and na is not None and na.needs_stats(training):
                 h, a, st = cv.forward_stats(h, na.norm == "instance", tag="d_conv"); tape.append(a)
@@ -700,7 +708,7 @@ class DiscriminatorPatchGAN(Model):
             if na is not None:
                 d = na.backward(tape.pop(), d, param_grads, which)
             d = cv.backward(tape.pop(), d, need_dx or i > 0, param_grads, which, tag="d_conv")
-            if bf and i == last:
+            if bf and i == last and not isinstance(cv, E.ConvCout1Bf16):
                 d = E.to_bf16_nhwc(rt, d)
             if bf and i == 1:
                 d = E.from_bf16_nhwc(rt, d)
@@ -811,6 +819,13 @@ class GanTrainer:
         self._loss_w = (1.0, 0.0)
         self.relativistic = bool(losses is not None and losses.relativistic)
         self.loss_kind = L.HEAD_KINDS[losses.loss_activation_name] if self.relativistic else L.HEAD_NONE
+        # fused=True (extension, SURVEY.md section 7 "three-graph semantics"): the step WITHOUT the reference's separate
+        # learning-phase-0 generator pass (train_gan3.py:346) -- the fakes the critic is trained on are those of the
+        # generator's one training-mode forward, which the generator step then re-uses: 3 G + 9 D forward-equivalents
+        # instead of 4 G + 9 D.  Default False: the faithful three-call step.
+        self.fused = False
+        self.coll_prof = None       # bench.py: {name: [(event0, event1), ...]} around every collective of data parallelism
+        self._pending = None
 
     # -- collectives (data parallelism; never inside a recorded segment) -------------------------------
     def _reduce_grads(self, model, which=0):
@@ -820,6 +835,30 @@ class GanTrainer:
             _dist.allreduce_sum(model.ps.grads if which == 0 else model.ps.grads2, self.pg)
 
     _sync_grads = _reduce_grads
+
+    def _timed_coll(self, name, fn):
+        """run one collective; with coll_prof set, bracket it with HIP events on the compute stream (the stream that waits
+        for it), so that event1 - event0 is the time the step is exposed to the collective"""
+        if self.coll_prof is None or not torch.cuda.is_available():
+            return fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r = fn()
+        e1.record()
+        self.coll_prof.setdefault(name, []).append((e0, e1))
+        return r
+
+    def _reduce_grads_start(self, model, which=0):
+        """DP: issue the bucket's all-reduce without waiting for it -- RCCL runs it on its own stream behind the work already
+        queued, the compute stream goes on with whatever does not read the bucket (the generator's forward, below)"""
+        if self.pg is not None:
+            from . import _dist
+            self._pending = _dist.allreduce_sum_start(model.ps.grads if which == 0 else model.ps.grads2, self.pg)
+
+    def _reduce_grads_wait(self):
+        h, self._pending = self._pending, None
+        if h is not None:
+            h.wait()
 
     def _reduce_means(self):
         """DP, relativistic losses: the two mean(D(.)) scalars pass through a non-linearity before back-prop, so they
@@ -899,11 +938,18 @@ class GanTrainer:
             L.check(rt.lib.vcg_fill(dy.data_ptr() + 4 * nreal, tot - nreal, -1.0 / tot, rt.stream), "vcg_fill")
             D.backward(s.pop("tape"), dy, False, True, 0)
 
+    def _gan_forward_g(self, s, lr):
+        """G forward with batch statistics (model.py:1103): independent of the critic's update, so under data parallelism it
+        runs while the critic's gradient bucket is being all-reduced"""
+        s["fake"], s["gtape"] = self.G.forward(lr, True)
+
     def _gan_forward(self, s, lr, hr):
         """G forward with batch statistics, frozen D on the fakes (and on the real batch for the relativistic loss),
         content loss value + gradient (model.py:1103-1123)"""
         rt, G, D = self.rt, self.G, self.D
-        fake, s["gtape"] = G.forward(lr, True)
+        if "fake" not in s:
+            self._gan_forward_g(s, lr)
+        fake = s.pop("fake")
         s["out_f"], s["dtape"] = D.forward(fake, True, False)          # frozen D: batch stats, no moving update
         _, s["dfake"] = _content_loss_and_grad(rt, self.content_kind, self.cw, fake, hr, out=self._lossbuf[2:3])
         E.mean_scalar(rt, s["out_f"], out=self._means[0:1])
@@ -927,18 +973,26 @@ class GanTrainer:
         s = {}
         dp = self.pg is not None
         rel_dp = dp and self.relativistic
-        P = [(False, lambda: self._disc_forward(s, hr, self.predict(lr)))]
+        tc = self._timed_coll
+        if self.fused:      # one training-mode generator forward serves the critic's step and the generator's
+            P = [(False, lambda: (self._gan_forward_g(s, lr), self._disc_forward(s, hr, s["fake"])))]
+        else:
+            P = [(False, lambda: self._disc_forward(s, hr, self.predict(lr)))]
         if rel_dp:
-            P.append((True, self._reduce_means))
+            P.append((True, lambda: tc("means_d_step", self._reduce_means)))
         P.append((False, lambda: self._disc_backward(s)))
         if dp:
-            P.append((True, lambda: self._reduce_grads(self.D)))
+            # the critic's bucket travels while the generator's training-mode forward (which reads no critic weight) runs
+            P.append((True, lambda: tc("d_bucket_issue", lambda: self._reduce_grads_start(self.D))))
+            if not self.fused:
+                P.append((False, lambda: self._gan_forward_g(s, lr)))
+            P.append((True, lambda: tc("d_bucket_wait", self._reduce_grads_wait)))
         P.append((False, lambda: (self._apply_adam(self.D, self.d_slots), self._gan_forward(s, lr, hr))))
         if rel_dp:
-            P.append((True, self._reduce_means))
+            P.append((True, lambda: tc("means_g_step", self._reduce_means)))
         P.append((False, lambda: self._gan_backward(s)))
         if dp:
-            P.append((True, lambda: self._reduce_grads(self.G)))
+            P.append((True, lambda: tc("g_bucket", lambda: self._reduce_grads(self.G))))
         P.append((False, lambda: self._apply_adam(self.G, self.g_slots)))
         return P
 
@@ -1010,30 +1064,36 @@ class GanTrainer:
     def gan_loss_values(self):
         return list(self.read_losses()[1:])
 
-    def train_step(self, lr, hr, read_losses=True):
+    def train_step(self, lr, hr, read_losses=True, fused=None):
         """One loop-body iteration (train_gan3.py:346-354) without host round trips between the three
-        calls; lr/hr are device NCHW tensors.  Returns (loss_disc, loss_gan, loss_gan_gen, loss_gan_disc)."""
+        calls; lr/hr are device NCHW tensors.  Returns (loss_disc, loss_gan, loss_gan_gen, loss_gan_disc).
+        fused=True/False switches ``self.fused`` (see __init__) for this and later steps."""
+        if fused is not None:
+            self.fused = bool(fused)
         for _, fn in self._plan(lr, hr):
             fn()
         return self.read_losses() if read_losses else None
 
     # -- hipGraph: the whole loop body as ONE graph launch (more under DP, cut at its collectives) ----------
-    def capture_train_step(self, lr, hr):
-        """Record the loop body for these (static-shape) device batches.  Later ``train_step_graph(lr, hr)`` copies the
+    def capture_train_step(self, lr, hr, fused=None):
+        """Record the loop body for these (static-shape) device batches (fused: see train_step; recorded as set here).  Later ``train_step_graph(lr, hr)`` copies the
         new frames into the captured input buffers and replays: ~700 kernel launches become one graph launch (no
         per-kernel host cost, no launch gaps) -- for every loss the reference offers, the relativistic ones included.
 
-        Under data parallelism the plan is cut at its collectives into several graphs (Wasserstein: three --
-            A: predict, D forward x2, D backward x2        -> all-reduce(D gradient bucket)
-            B: Adam(D), G forward, D forward, D/G backward -> all-reduce(G gradient bucket)
-            C: Adam(G)
-        relativistic: five, with the two 2-float mean all-reduces in addition) and the RCCL calls are issued eagerly
+        Under data parallelism the plan is cut at its collectives into several graphs (Wasserstein: four --
+            A: predict, D forward x2, D backward x2        -> all-reduce(D gradient bucket) issued, not waited for
+            B: G forward (training mode)                   -> wait for the bucket (it travelled under B)
+            C: Adam(D), D forward, D/G backward            -> all-reduce(G gradient bucket)
+            D: Adam(G)
+        relativistic: six, with the two 2-float mean all-reduces in addition) and the RCCL calls are issued eagerly
         between the replays: nothing about RCCL graph capture is assumed.
 
         Every lazily cached derived weight (per-tap transposed kernels, packed bf16 copies) is invalidated before the
         recording, so its derivation is part of the graph at each point of use: weights changed from outside between two
         replays (load_state, set_weights_dict, a broadcast) are picked up by the next replay."""
         rt = self.rt
+        if fused is not None:
+            self.fused = bool(fused)
         if self._t_dev is None:
             self._t_dev = torch.tensor([self.opt.iterations, 0], dtype=torch.int32, device=rt.device)    # {t, lr_t scratch}
         self._g_lr, self._g_hr = lr.clone(), hr.clone()
@@ -1142,9 +1202,10 @@ class TrainingModel:
 
 
 def _make(generator, discriminator, wiring, content_loss, content_loss_weight, losses, discriminator_loss_weight,
-          optimizer, process_group):
+          optimizer, process_group, fused_step=False):
     trainer = GanTrainer(generator, discriminator, wiring, _content_kind(content_loss), content_loss_weight, losses,
                          discriminator_loss_weight, optimizer, process_group)
+    trainer.fused = bool(fused_step)
     discriminator.trainable = False     # state the reference leaves behind (model.py:1040,1101)
     return (TrainingModel(trainer, "gen", "generator_training_model"),
             TrainingModel(trainer, "disc", "discriminator_training_model"),
@@ -1152,26 +1213,30 @@ def _make(generator, discriminator, wiring, content_loss, content_loss_weight, l
 
 
 def make_and_compile_gan(generator, discriminator, input_shape, output_shape, content_loss, content_loss_weight,
-                         discriminator_loss, discriminator_loss_weight, optimizer=_DEFAULT_ADAM, process_group=None):
-    """model.py:1017-1051 (v1 wiring; discriminator_loss must be ``wasserstein_loss``)."""
+                         discriminator_loss, discriminator_loss_weight, optimizer=_DEFAULT_ADAM, process_group=None,
+                         fused_step=False):
+    """model.py:1017-1051 (v1 wiring; discriminator_loss must be ``wasserstein_loss``).  ``process_group`` (data parallelism) and
+    ``fused_step`` (GanTrainer.fused: the train_step()/hipGraph fast path without the separate predict pass; the three Keras-style
+    calls are unaffected) are extensions."""
     if discriminator_loss is not wasserstein_loss:
         raise NotImplementedError("v1 wiring is implemented for discriminator_loss=wasserstein_loss (train_gan.py:267)")
     _check_shapes(generator, discriminator, input_shape, output_shape)
     return _make(generator, discriminator, "v1", content_loss, content_loss_weight, None, discriminator_loss_weight,
-                 optimizer, process_group)
+                 optimizer, process_group, fused_step)
 
 
 def make_and_compile_gan2(generator, discriminator, input_shape, output_shape, content_loss, content_loss_weight,
-                          discriminator_losses, discriminator_loss_weight, optimizer=_DEFAULT_ADAM, process_group=None):
+                          discriminator_losses, discriminator_loss_weight, optimizer=_DEFAULT_ADAM, process_group=None,
+                          fused_step=False):
     """model.py:1057-1125.  ``discriminator_losses`` is a zero-argument factory, called twice like the
-    reference does (:1085,:1110)."""
+    reference does (:1085,:1110).  ``process_group`` / ``fused_step``: extensions, see make_and_compile_gan."""
     _check_shapes(generator, discriminator, input_shape, output_shape)
     losses = discriminator_losses()
     discriminator_losses()
     if not isinstance(losses, GanLosses):
         raise TypeError("discriminator_losses() must return a GanLosses instance")
     return _make(generator, discriminator, "gan2", content_loss, content_loss_weight, losses,
-                 discriminator_loss_weight, optimizer, process_group)
+                 discriminator_loss_weight, optimizer, process_group, fused_step)
 
 
 def _check_shapes(generator, discriminator, input_shape, output_shape):
