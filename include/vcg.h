@@ -325,6 +325,31 @@ int vcg_conv9x9_to3_bf16_dgrad_chsum(const vcg_conv_desc* d, const void* dy, con
 int vcg_conv9x9_from3_bf16_fwd(const vcg_conv_desc* d, const void* x, const void* wfrag, const void* bias, const void* prelu_alpha,
                                void* y, hipStream_t stream);
 
+/* Conv2D on THREE input channels from the fp32 NCHW frames to bf16 NHWC, + bias + LeakyReLU(lrelu_slope; 1 = none): the critics' first
+ * layer where it enters the bf16 layout -- Conv2D(64, 3) 'same' (upscaling/upscaler/model.py:839, simple_512 / thin_512; its BatchNormalization
+ * follows on bf16) and the PatchGAN's Conv2D(64, 4, strides 2) + LeakyReLU(0.2).  3x3 stride 1 and 4x4 stride 2, cout = 64*{1,2,4,8}; d carries
+ * the pads.  wfrag: vcg_conv3ch_bf16_wfrag_bytes(kh, kw, cout) bytes made by vcg_pack_conv3ch_bf16 from Keras' (kh,kw,3,cout) kernel. */
+size_t vcg_conv3ch_bf16_wfrag_bytes(int32_t kh, int32_t kw, int32_t cout);
+int vcg_pack_conv3ch_bf16(const void* w, int32_t kh, int32_t kw, int32_t cout, void* out, hipStream_t stream);
+int vcg_conv3ch_bf16_fwd(const vcg_conv_desc* d, const void* x, const void* wfrag, const void* bias, float lrelu_slope, void* y, hipStream_t stream);
+/* data gradient of such a first layer from the bf16 NHWC gradient dz [n][oh][ow][64] in front of its activation to the fp32 NCHW gradient
+ * of the frames [n][3][h][w] (what the generator's backward consumes): the 3-channel result is computed as 12 (4x4 stride 2: four sub-pixel
+ * phases x 3) or 3 of 64 virtual output channels of a 3x3 stride-1 convolution over dz on vcg_conv2d_nhwc_bf16_fwd and scattered.
+ * cout = 64, pads 1; w_hwio: Keras' (kh,kw,3,64) kernel (fp32; its bf16 copy is the operand). */
+size_t vcg_conv3ch_bf16_dgrad_workspace_bytes(const vcg_conv_desc* d);
+int vcg_conv3ch_bf16_dgrad(const vcg_conv_desc* d, const void* dz, const float* w_hwio, float* dx, void* ws, size_t ws_bytes, vcg_stream_t stream);
+/* the training-mode form of vcg_conv9x9_from3_bf16_fwd: also stores z, the value in front of the PReLU (bf16 NHWC like y), which
+ * vcg_prelu_bwd_nhwc_bf16 needs */
+int vcg_conv9x9_from3_bf16_fwd_train(const vcg_conv_desc* d, const void* x, const void* wfrag, const void* bias, const void* prelu_alpha,
+                                     void* y, void* z, hipStream_t stream);
+/* backward of that PReLU (initial/prelu, upscaling/upscaler/model.py:276) where the bf16 trunk begins: d1 (+ d2, optional: the long skip's
+ * gradient, model.py:285) bf16 NHWC [n][hw][c] -> dz_nchw fp32 [n][c][hw] = (d1 + d2) * (z >= 0 ? 1 : alpha[c]) -- the layout
+ * vcg_conv2d_wgrad reads -- and records [vcg_prelu_bwd_nhwc_bf16_records(n, hw)][c] whose sum (vcg_sum_records) is the slope gradient
+ * sum((d1 + d2) * z, z < 0).  c % 8 == 0. */
+int vcg_prelu_bwd_nhwc_bf16_records(int n, int hw);
+int vcg_prelu_bwd_nhwc_bf16(const void* d1, const void* d2, const void* z, const float* prelu_alpha, int n, int c, int hw, float* dz_nchw,
+                            float* records, hipStream_t stream);
+
 /* BatchNormalization / instance norm (+PReLU / LeakyReLU, +Add) on bf16 NHWC activations (model.py:20-25): statistics
  * and arithmetic in fp32.  vcg_norm_stats_bf16: per-channel (VCG_NORM_BATCH) or per-(n,c) (VCG_NORM_INSTANCE) mean and
  * biased variance, c % 8 == 0, c <= 256; feed them to vcg_norm_finalize (shared with the fp32 path) for scale / shift and

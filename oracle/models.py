@@ -99,13 +99,17 @@ def init_upscaler_orig(output_image_shape, kernel_size=5, filters=64, upscale_fa
 
 
 def upscaler_orig_forward(w, x_nhwc, training, res_block_num, upscale_factor, taps=None, norm="batch", trunk_bf16=False, tail_bf16=False,
-                          fold_inference=True):
+                          fold_inference=True, init_bf16=None):
     """x_nhwc: [N,h,w,3] -> ([N,h*f,w*f,3], bn_updates).  ``training`` selects batch vs moving BN
     statistics (Keras learning phase: predict=0, train_on_batch=1).  ``taps`` (optional dict)
     receives named NCHW intermediates for kernel-level parity tests.  ``trunk_bf16`` marks the tensors the
     product's ``trunk_dtype='bf16'`` mode stores in bf16 (values and gradients; keras_ops.bf16_*); ``tail_bf16`` adds those of
     ``'bf16+tail'`` (up-sampling block and final/conv).  ``fold_inference``: in learning phase 0 the product's bf16 trunk applies the
-    BatchNormalization in the convolution's epilogue, so the convolution's own output is never stored (no rounding there)."""
+    BatchNormalization in the convolution's epilogue, so the convolution's own output is never stored (no rounding there).
+    ``init_bf16`` (default: as ``tail_bf16``): initial/conv reads bf16 copies of the frames and of its kernel (the product's
+    InitialConv9x9Bf16; fp32 accumulation, fp32 weight gradient from the fp32 frames -- the straight-through gradient of the rounding)."""
+    if init_bf16 is None:
+        init_bf16 = tail_bf16
     upd = OrderedDict()
     st = K.bf16_store if trunk_bf16 else (lambda v: v)
     rf = K.bf16_round_fwd if trunk_bf16 else (lambda v: v)
@@ -133,7 +137,11 @@ def upscaler_orig_forward(w, x_nhwc, training, res_block_num, upscale_factor, ta
         return t
 
     x = x_nhwc.permute(0, 3, 1, 2)
-    m = tap("initial/prelu", K.prelu(tap("initial/conv", conv(x, "initial/conv")), w["initial/prelu/alpha"]))
+    if init_bf16:
+        c0 = K.conv2d(K.bf16_round_fwd(x), K.bf16_round_fwd(w["initial/conv/kernel"]), w["initial/conv/bias"], 1, "same")
+    else:
+        c0 = conv(x, "initial/conv")
+    m = tap("initial/prelu", K.prelu(tap("initial/conv", c0), w["initial/prelu/alpha"]))
     skip = rf(m)                     # long skip: bf16 copy of the fp32 tensor, its gradient stays fp32
     m = st(m)
     for i in range(res_block_num):
@@ -285,8 +293,8 @@ def init_discriminator_512(input_shape, variant="simple", seed=11):
 
 def discriminator_512_forward(w, x_nhwc, training, activation="none", taps=None, bf16=False):
     """make_discriminator_simple_512 / _thin_512 forward: [N,H,W,3] -> ([N,1], bn_updates).  ``bf16`` marks the tensors the
-    product's ``dtype='bf16'`` mode stores in bf16 (blocks 2..9: convolution and normalisation outputs, values and gradients; bf16
-    copies of the fp32 master kernels) -- keras_ops.bf16_*."""
+    product's ``dtype='bf16'`` mode stores in bf16 (every block's convolution and normalisation outputs, values and gradients; bf16
+    copies of the fp32 master kernels and, at block 1, of the frames) -- keras_ops.bf16_*."""
     upd = OrderedDict()
     st = K.bf16_store if bf16 else (lambda v: v)
     rf = K.bf16_round_fwd if bf16 else (lambda v: v)
@@ -303,8 +311,9 @@ def discriminator_512_forward(w, x_nhwc, training, activation="none", taps=None,
     while ("discriminator/block_%d/Conv2d/kernel" % i) in w:
         n = "discriminator/block_%d" % i
         if i == 1:
-            m = K.conv2d(m, w[n + "/Conv2d/kernel"], w[n + "/Conv2d/bias"], 1, "same")
-            m = st(K.leaky_relu(bn(m, n + "/BatchNorm"), 0.1))            # fp32 block; its output enters the bf16 layout
+            # block 1 enters the bf16 layout: bf16 copies of the frames and of the kernel as operands (fp32 accumulation), output stored in bf16
+            m = st(K.conv2d(rf(m), rf(w[n + "/Conv2d/kernel"]), w[n + "/Conv2d/bias"], 1, "same"))
+            m = st(K.leaky_relu(bn(m, n + "/BatchNorm"), 0.1))
         else:
             m = st(K.conv2d(m, rf(w[n + "/Conv2d/kernel"]), w[n + "/Conv2d/bias"], 2, "same"))
             m = st(K.leaky_relu(bn(m, n + "/BatchNorm"), 0.1))
@@ -391,6 +400,8 @@ def discriminator_patchgan_70_forward(w, x_nhwc, training, activation="none", no
         n = "discriminator/block_%d" % (i + 1)
         if kind == "norm":
             m = st(K.conv2d(m, rf(w[n + "/Conv2d/kernel"]), w[n + "/Conv2d/bias"], s, 1))
+        elif i == 0:      # block 1 enters the bf16 layout: bf16 copies of the frames and of the kernel as operands, fp32 accumulation
+            m = K.conv2d(rf(m), rf(w[n + "/Conv2d/kernel"]), w[n + "/Conv2d/bias"], s, 1)
         else:
             m = K.conv2d(m, w[n + "/Conv2d/kernel"], w[n + "/Conv2d/bias"], s, 1)
         if kind == "norm":

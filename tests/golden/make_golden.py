@@ -28,6 +28,10 @@ CASES = {
     # batch 2: the inference output (stored sub-sampled 8x8 plus its sums) and the losses of the first step.  Only with
     # `python make_golden.py c2` (about two minutes of fp64 CPU time).
     "c2": dict(batch=2, res=9, k=3, disc="patch", losses="wass", dw=1e-5, steps=1, lr=256, sub=8),
+    # BASELINE.json configs[2]'s arithmetic (C3: bf16 storage in G and D, fp32 accumulation) at its FULL frame size, batch 2: the oracle
+    # marks every tensor the product stores in bf16 (keras_ops.bf16_*: upscaler_orig_forward(trunk_bf16, tail_bf16), PatchGAN bf16=True).
+    # `python make_golden.py c3`
+    "c3": dict(batch=2, res=9, k=3, disc="patch", losses="wass", dw=1e-5, steps=1, lr=256, sub=8, bf16=True),
 }
 
 
@@ -39,13 +43,14 @@ def build(case):
     c = CASES[case]
     hr = 2 * c.get("lr", 64)
     gw = M.init_upscaler_orig((hr, hr, 3), c["k"], 64, 2, c["res"], seed=7)
+    bf = bool(c.get("bf16"))
     if c["disc"] == "patch":
         dw = M.init_discriminator_patchgan_70((hr, hr, 3), seed=11)
-        df = lambda w, x, t: M.discriminator_patchgan_70_forward(w, x, t)
+        df = lambda w, x, t: M.discriminator_patchgan_70_forward(w, x, t, bf16=bf)
     else:
         dw = M.init_discriminator_512((hr, hr, 3), c["disc"], seed=11)
-        df = lambda w, x, t: M.discriminator_512_forward(w, x, t)
-    gf = lambda w, x, t: M.upscaler_orig_forward(w, x, t, c["res"], 2)
+        df = lambda w, x, t: M.discriminator_512_forward(w, x, t, bf16=bf)
+    gf = lambda w, x, t: M.upscaler_orig_forward(w, x, t, c["res"], 2, trunk_bf16=bf, tail_bf16=bf)
     return c, gw, dw, gf, df
 
 
@@ -80,9 +85,39 @@ def run(case, dtype=torch.float64):
     return out
 
 
+def randomize_norm(w, seed):
+    """non-trivial BatchNormalization statistics / affine parameters / PReLU slopes, as after training (shared by fixture and test)"""
+    rng = np.random.RandomState(seed)
+    for k, v in w.items():
+        if k.endswith("/gamma"):
+            w[k] = rng.uniform(0.7, 1.3, v.shape).astype(np.float32)
+        elif k.endswith(("/beta", "/moving_mean", "/bias")):
+            w[k] = rng.uniform(-0.2, 0.2, v.shape).astype(np.float32)
+        elif k.endswith("/moving_variance"):
+            w[k] = rng.uniform(0.5, 1.5, v.shape).astype(np.float32)
+        elif k.endswith("/alpha"):
+            w[k] = rng.uniform(0.0, 0.3, v.shape).astype(np.float32)
+    return w
+
+
+def run_c5():
+    """BASELINE.json configs[4] (inference-only generator, bf16, 256 -> 512, 9 blocks): learning-phase-0 forward of FOUR distinct frames with
+    the storage roundings of the product's inference engine (BatchNormalization folded: the convolution outputs are never stored), fp64.
+    The GPU test replicates the four frames to the configuration's batch of 32 (frames are independent in inference)."""
+    gw = randomize_norm(M.init_upscaler_orig((512, 512, 3), 3, 64, 2, 9, seed=7), 3)
+    x = torch.tensor(frames(300, 4, 256, 256), dtype=torch.float64)
+    with torch.no_grad():
+        y, _ = M.upscaler_orig_forward(M.to_torch(gw, torch.float64), x, False, 9, 2, trunk_bf16=True, tail_bf16=True)
+        y32, _ = M.upscaler_orig_forward(M.to_torch(gw, torch.float32), x.float(), False, 9, 2, trunk_bf16=True, tail_bf16=True)
+    y = y.numpy()
+    return {"predict_sub": y[:, ::8, ::8].astype(np.float32),
+            "predict_sums": np.stack([np.asarray([f.sum(), np.abs(f).sum(), (f * f).sum()], np.float64) for f in y]),
+            "fp32_emulation_err": np.asarray([float(np.max(np.abs(y32.double().numpy() - y)) / np.max(np.abs(y)))], np.float64)}
+
+
 if __name__ == "__main__":
-    for case in (sys.argv[1:] or [c for c in CASES if c != "c2"]):
-        res = run(case)
+    for case in (sys.argv[1:] or [c for c in CASES if c not in ("c2", "c3", "c5")]):
+        res = run_c5() if case == "c5" else run(case)
         path = os.path.join(HERE, case + ".npz")
         np.savez_compressed(path, **res)
-        print(case, os.path.getsize(path) // 1024, "KiB", res["losses"].tolist())
+        print(case, os.path.getsize(path) // 1024, "KiB", res["losses"].tolist() if "losses" in res else "")

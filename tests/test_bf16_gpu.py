@@ -722,6 +722,50 @@ def test_cout1_conv_bf16_fwd_dgrad_wgrad(rt, cin, k, padding, n, h, w):
     assert torch.equal(g1, ps.grad("c/kernel"))
 
 
+@pytest.mark.parametrize("cout,k,stride,padding,slope,n,h,w", [
+    (64, 4, 2, 1, 0.2, 2, 64, 64),           # PatchGAN block 1
+    (64, 4, 2, 1, 0.2, 1, 70, 54),           # ragged tiles (35 x 27 outputs)
+    (64, 4, 2, 1, 0.2, 3, 33, 47),           # odd sizes: the last row / column of taps falls into the padding
+    (64, 3, 1, "same", None, 2, 40, 72),     # simple_512 / thin_512 block 1 (model.py:839): no activation (BatchNormalization follows)
+    (128, 3, 1, "same", 0.1, 1, 25, 33),     # two output-channel blocks
+])
+def test_first_conv_bf16_forward_and_gradients(rt, cout, k, stride, padding, slope, n, h, w):
+    """FirstConvBf16 (vcg_conv3ch_bf16_fwd: fp32 NCHW frames -> bf16 NHWC, + bias + LeakyReLU) against the fp64 oracle on the same
+    bf16-rounded frames / kernel: output to 2^-8; weight / bias gradients (fp32 kernels on the fp32 frames, given the gradient in front of
+    the activation) to 1e-5 against autograd of the UNROUNDED convolution (the straight-through gradient of the roundings); the data
+    gradient (vcg_conv3ch_bf16_dgrad: bf16 kernel copy, virtual-channel convolution stored in bf16) to 2^-8."""
+    from oracle import keras_ops as K
+    from upscaler import _engine as E, _lib as L
+    layer = E.FirstConvBf16("c", 3, cout, k, stride, padding, L.ACT_LRELU if slope else L.ACT_NONE, slope or 0.0)
+    ps = E.ParamStore()
+    layer.declare(ps)
+    ps.materialize(rt)
+    layer.bind(rt, ps)
+    g = torch.Generator().manual_seed(cout + k * 7 + h)
+    wk = torch.randn(k, k, 3, cout, generator=g) * (2.0 / (k * k * 3)) ** 0.5
+    bk = torch.randn(cout, generator=g) * 0.1
+    ps.set_weights({"c/kernel": wk.numpy(), "c/bias": bk.numpy()})
+    x = torch.randint(0, 256, (n, 3, h, w), generator=g).float() / 127.5 - 1
+    z = K.conv2d(_bf16_round(x), _bf16_round(wk), bk.double(), stride, padding)
+    yr = K.leaky_relu(z, slope) if slope else z
+    y, ctx = layer.forward(x.to(rt.device).contiguous())
+    assert tuple(y.shape) == (n, yr.shape[2], yr.shape[3], cout)
+    e_y = rel_err(_to_nchw_f32(rt, y), yr)
+    # backward: dz given in bf16 NHWC
+    dz = _bf16_round(torch.randn(*yr.shape, generator=g)).float()
+    xg = x.double().requires_grad_(True)
+    wg = wk.double().requires_grad_(True)
+    bg = bk.double().requires_grad_(True)
+    (K.conv2d(xg, wg, bg, stride, padding) * dz.double()).sum().backward()
+    xr = x.double().requires_grad_(True)          # the data gradient multiplies by the bf16 copy of the kernel and is stored in bf16 on its way
+    (K.conv2d(xr, _bf16_round(wk), bk.double(), stride, padding) * dz.double()).sum().backward()
+    dx = layer.backward(ctx, _to_nhwc_bf16(rt, dz.to(rt.device)), True, True, 0)
+    e_dx, e_dw, e_db = rel_err(dx, xr.grad), rel_err(ps.grad("c/kernel"), wg.grad), rel_err(ps.grad("c/bias"), bg.grad)
+    report("first conv bf16 3->%d k%d s%d pad=%s n=%d %dx%d: fwd=%.2e dgrad=%.2e wgrad=%.2e dbias=%.2e" % (cout, k, stride, padding, n, h, w, e_y, e_dx, e_dw, e_db))
+    assert e_y < TOL_BF16 and e_dx < TOL_BF16
+    assert e_dw < 1e-5 and e_db < 1e-5
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # bf16 discriminators and the all-bf16 train step (BASELINE.json configs C3 / C4)
 # ---------------------------------------------------------------------------------------------------------------
@@ -733,7 +777,8 @@ def _l2(a, b, floor=0.0):
 def test_bf16_discriminator_forward_and_gradients(rt, kind):
     """make_discriminator_*(..., dtype='bf16'): training-mode forward, input gradient and every parameter gradient against the
     fp64 oracle evaluated with the same storage roundings; yardstick per tensor = that tensor's own distance between the fp32
-    and fp64 runs of the same emulation (bound 2.5x, floor 1e-2; numerically-zero gradients excluded and reported)."""
+    and fp64 runs of the same emulation (bound 2.5x, floor 1e-2 or half the median such distance over the network's tensors;
+    numerically-zero gradients excluded and reported)."""
     from oracle import models as M
     from upscaler import model as PM, _engine as E
     n, hw = 4, 64
@@ -767,16 +812,22 @@ def test_bf16_discriminator_forward_and_gradients(rt, kind):
     e_dx, e32_dx = _l2(E.to_nhwc(rt, dx).cpu().double(), dxr), _l2(dx32, dxr)
     gmax = max(float(g.abs().max()) for g in gref.values())
     worst = 0.0
+    floors = {k: 1e-4 * gmax * b.numel() ** 0.5 for k, b in gref.items()}
+    # the error LEVEL of this network in any fp32 evaluation (BatchNormalization over a handful of samples on the 1x1 maps of the last
+    # blocks makes the Dense-head critics chaotic, fact (i) of DESIGN.md section 5): a tensor whose own fp32-vs-fp64 distance happens to be
+    # ~0 (a gradient that is a plain sum, like the last beta) is still computed from tensors that carry that level
+    e32_all = sorted(_l2(g32[k], b, floors[k]) for k, b in gref.items() if float(b.norm()) >= floors[k])
+    level = e32_all[len(e32_all) // 2]
     for k, b in gref.items():
         a = D.ps.grad(k).cpu().double()
-        floor = 1e-4 * gmax * b.numel() ** 0.5
+        floor = floors[k]
         real = float(b.norm()) >= floor
         e, e32 = _l2(a, b, floor), _l2(g32[k], b, floor)
         report("    bf16 D[%s] %-44s |g|2=%.2e rel L2 err=%.2e (oracle fp32-vs-fp64, same storage: %.2e)%s"
                % (kind, k, float(b.norm()), e, e32, "" if real else "   [zero gradient: excluded]"))
         if real:
             worst = max(worst, e)
-            assert e < max(1e-2, 2.5 * e32), (k, e, e32)
+            assert e < max(1e-2, 2.5 * e32, 0.5 * level), (k, e, e32, level)
     report("bf16 discriminator %s: output err=%.2e (yardstick %.2e; vs un-rounded oracle %.2e)  input-gradient err=%.2e (yardstick %.2e)  worst parameter gradient=%.2e"
            % (kind, e_y, e32_y, _l2(yd, yp), e_dx, e32_dx, worst))
     assert e_y < max(2e-3, 2.5 * e32_y) and e_dx < max(1e-2, 2.5 * e32_dx)

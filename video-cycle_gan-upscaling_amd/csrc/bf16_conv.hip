@@ -124,6 +124,69 @@ __global__ void bf16_nhwc_to_f32_nchw_kernel(const __bf16* __restrict__ x, float
     }
 }
 
+// PReLU backward at the entry of the bf16 trunk (initial/prelu, model.py:276): the two gradients that meet at its output -- the trunk's and
+// the long skip's (model.py:285), both bf16 NHWC -- are added, multiplied by the activation's derivative (sign of the stored pre-activation
+// z) and written as the fp32 NCHW tensor the 3-channel convolution's weight-gradient kernel reads; the slope gradient sum(d * z, z < 0)
+// leaves as one record of c floats per workgroup (summed in a fixed order by sum_records_kernel).  c % 8 == 0, c <= 64 * gridDim-free loop.
+__global__ __launch_bounds__(256) void prelu_bwd_bf16_to_f32_nchw_kernel(const __bf16* __restrict__ d1, const __bf16* __restrict__ d2,
+                                                                         const __bf16* __restrict__ z, const float* __restrict__ alpha,
+                                                                         float* __restrict__ dz, float* __restrict__ rec, int c, int hw, int tiles) {
+    __shared__ float tile[64][65];
+    __shared__ float red[32][64];
+    const int img = blockIdx.y, tid = threadIdx.x;
+    const int ch = (tid & 7) * 8;                       // this thread's channel octet inside a 64-channel chunk (the same in both passes below)
+    for (int c0 = 0; c0 < c; c0 += 64) {
+        float da[8], al[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            da[j] = 0.f;
+            al[j] = c0 + ch + j < c ? alpha[c0 + ch + j] : 0.f;
+        }
+        for (int t = blockIdx.x; t < tiles; t += gridDim.x) {
+            const int p0 = t * 64;
+#pragma unroll
+            for (int e = tid; e < 64 * 8; e += 256) {
+                const int pp = e >> 3;
+                float g[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) g[j] = 0.f;
+                if (c0 + ch < c && p0 + pp < hw) {
+                    const long o = ((long)img * hw + p0 + pp) * c + c0 + ch;
+                    const bf16x8 a = *(const bf16x8*)(d1 + o), zz = *(const bf16x8*)(z + o);
+                    bf16x8 b;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) b[j] = (__bf16)0.f;
+                    if (d2) b = *(const bf16x8*)(d2 + o);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float d = (float)a[j] + (float)b[j], zf = (float)zz[j];
+                        g[j] = zf >= 0.f ? d : d * al[j];
+                        da[j] += zf >= 0.f ? 0.f : d * zf;
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) tile[ch + j][pp] = g[j];
+            }
+            __syncthreads();
+            for (int e = tid; e < 64 * 64; e += 256) {
+                const int cc = e >> 6, pp = e & 63;
+                if (c0 + cc < c && p0 + pp < hw) dz[((long)img * c + c0 + cc) * hw + p0 + pp] = tile[cc][pp];
+            }
+            __syncthreads();
+        }
+        // the 32 threads that share a channel octet add up in a fixed order
+#pragma unroll
+        for (int j = 0; j < 8; ++j) red[tid >> 3][ch + j] = da[j];
+        __syncthreads();
+        if (tid < 64 && c0 + tid < c) {
+            float s = 0.f;
+            for (int k = 0; k < 32; ++k) s += red[k][tid];
+            rec[((long)img * gridDim.x + blockIdx.x) * c + c0 + tid] = s;
+        }
+        __syncthreads();
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // 3x3 stride-1 'same' convolution, 64 -> 64 channels: the generator trunk
 // ---------------------------------------------------------------------------------------------------------------
@@ -690,13 +753,22 @@ __global__ __launch_bounds__(V2_NT, 1) void conv3x3_c64_bf16_v2_kernel(C3Params 
 // taps kx = 9..11 carry zero weights) = 27, against 36 of the 64-channel 3x3 convolution.  Same skeleton as
 // conv3x3_c64_bf16_kernel: 6 compute + 2 loader waves, weights (54 KiB of operand fragments) resident in LDS,
 // 12x32-pixel tiles, permlane-swapped 16-byte stores.  The kernel is bound by its 128 bytes of output per pixel.
-constexpr int I_HR = TR + 8;                 // halo rows
-constexpr int I_HC = 44;                     // 32 + 8 halo columns + 3 (kx up to 11) + 1
-constexpr int I_ROWB = I_HC * 8;
-constexpr int I_XB = I_HR * I_ROWB;          // 7040 B
-constexpr int I_WB = 27 * 64 * 32;           // 55296 B: [k-step][out-channel][half][8 bf16]
-constexpr int I_NPIX = I_HR * I_HC;          // 880 pixels per halo tile
-constexpr int I_NPRE = (I_NPIX + NLW * 64 - 1) / (NLW * 64);      // 7 pixels per loader lane
+// The same kernel serves every convolution ON THREE INPUT CHANNELS (template <KH, NG, S>: KH kernel rows, NG groups of 4 kernel columns,
+// stride S): 9x9 stride 1 above (KH 9, NG 3), the critics' first layers -- 4x4 stride 2 (PatchGAN block 1: KH 4, NG 1, S 2) and 3x3 stride 1
+// (simple_512 / thin_512 block 1, model.py:839: KH 3, NG 1) -- with bias + LeakyReLU / PReLU in the epilogue.  An output tile of 12x32
+// pixels reads a halo of (12 S + KH - S) x (31 S + 4 NG + 1) input pixels; lane r's fragment sits at column r S + 4 j + 2 hh.
+template <int KH, int NG, int S>
+struct I3Cfg {
+    static constexpr int HR = TR * S + KH - S;                    // halo rows           (9x9: 20)
+    static constexpr int HC = (31 * S + 4 * NG + 2) & ~1;         // halo columns, even  (9x9: 44)
+    static constexpr int ROWB = HC * 8;
+    static constexpr int XB = (HR * ROWB + 15) & ~15;             // 9x9: 7040 B
+    static constexpr int NK = KH * NG;                            // k-steps of 16
+    static constexpr int WB = NK * 64 * 32;                       // 9x9: 55296 B: [k-step][out-channel][half][8 bf16]
+    static constexpr int NPIX = HR * HC;                          // 9x9: 880 pixels per halo tile
+    static constexpr int NPRE = (NPIX + NLW * 64 - 1) / (NLW * 64);       // pixels per loader lane (9x9: 7)
+    static constexpr int LDS = WB + XB + 512;
+};
 
 struct I9Params {
     const float* x;          // fp32 NCHW [n][3][h][w]
@@ -704,13 +776,19 @@ struct I9Params {
     const float* bias;       // [cout] or null
     const float* alpha;      // PReLU slopes [cout] or null (none)
     __bf16* y;               // bf16 NHWC [n][h][w][cout]
+    __bf16* z;               // optional bf16 NHWC [n][h][w][cout]: the value in front of the PReLU (its backward needs the sign and, for the slope gradient, the value)
     const __bf16* mask;      // optional bf16 NHWC [n][h][w][cout]: y *= (mask > 0 ? 1 : mask_slope)  (data gradient in front of a LeakyReLU)
     float mask_slope;
     float* chsum;            // optional [workgroups per channel block * 6][cout]: per-wave sums of the stored output per channel (a bias gradient)
-    int n, h, w_, cout, tiles_x, tiles_y, total;        // cout = 64 * nblk; workgroup b serves channel block b % nblk
+    int n, h, w_, cout, tiles_x, tiles_y, total;        // cout = 64 * nblk; workgroup b serves channel block b % nblk; h, w_: INPUT size
+    int oh, ow, pad_top, pad_left;                      // output size and the 'before' pads (9x9 'same': h, w_, 4, 4)
+    float slope;                                        // without alpha: LeakyReLU slope (1 = no activation)
 };
 
-__global__ __launch_bounds__(NT, 1) void conv9x9_c3to64_bf16_kernel(I9Params p) {
+template <int KH, int NG, int S>
+__global__ __launch_bounds__(NT, 1) void conv_c3to64_bf16_kernel(I9Params p) {
+    using C = I3Cfg<KH, NG, S>;
+    constexpr int I_HC = C::HC, I_ROWB = C::ROWB, I_XB = C::XB, I_WB = C::WB, I_NPIX = C::NPIX, I_NPRE = C::NPRE, NK = C::NK;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* wl = smem;
     unsigned char* xl = smem + I_WB;
@@ -722,7 +800,7 @@ __global__ __launch_bounds__(NT, 1) void conv9x9_c3to64_bf16_kernel(I9Params p) 
     for (int c = tid; c < I_WB / 16; c += NT) ((uint4*)wl)[c] = p.w[(long)cb * (I_WB / 16) + c];
     if (tid < 64) {
         prm[tid] = p.bias ? p.bias[cb * 64 + tid] : 0.f;
-        prm[64 + tid] = p.alpha ? p.alpha[cb * 64 + tid] : 1.f;
+        prm[64 + tid] = p.alpha ? p.alpha[cb * 64 + tid] : p.slope;
     }
     const long plane = (long)p.h * p.w_;
 
@@ -731,7 +809,7 @@ __global__ __launch_bounds__(NT, 1) void conv9x9_c3to64_bf16_kernel(I9Params p) 
         float pre[I_NPRE][3];
         auto fetch = [&](int tile) {
             const int txi = tile % p.tiles_x, t2 = tile / p.tiles_x, tyi = t2 % p.tiles_y, img = t2 / p.tiles_y;
-            const int y0 = tyi * TR - 4, x0 = txi * TC - 4;
+            const int y0 = tyi * TR * S - p.pad_top, x0 = txi * TC * S - p.pad_left;
             const float* xi = p.x + (long)img * 3 * plane;
 #pragma unroll
             for (int i = 0; i < I_NPRE; ++i) {
@@ -774,7 +852,7 @@ __global__ __launch_bounds__(NT, 1) void conv9x9_c3to64_bf16_kernel(I9Params p) 
     }
 
     const int aoff = r * 32 + hh * 16;                         // weight fragment of (co = r [+32], half)
-    const unsigned char* xb = xl + (wv * 2) * I_ROWB + (r + 2 * hh) * 8;
+    const unsigned char* xb = xl + (wv * 2 * S) * I_ROWB + (r * S + 2 * hh) * 8;
     float csum[32];                                            // p.chsum: this lane's 32 channels [mt][q][j], summed over its pixels
 #pragma unroll
     for (int i = 0; i < 32; ++i) csum[i] = 0.f;
@@ -783,7 +861,7 @@ __global__ __launch_bounds__(NT, 1) void conv9x9_c3to64_bf16_kernel(I9Params p) 
     for (int tile = wg0; tile < p.total; tile += nwg) {
         const int txi = tile % p.tiles_x, t2 = tile / p.tiles_x, tyi = t2 % p.tiles_y, img = t2 / p.tiles_y;
         const int gx = txi * TC + r, gy0 = tyi * TR + wv * 2;
-        const bool okx = gx < p.w_;
+        const bool okx = gx < p.ow;
 
         f32x16 acc[2][2];
 #pragma unroll
@@ -795,21 +873,21 @@ __global__ __launch_bounds__(NT, 1) void conv9x9_c3to64_bf16_kernel(I9Params p) 
 
         bf16x8 fa[2][2], fb[2][2];
         auto frag = [&](auto ic) {
-            constexpr int i = decltype(ic)::value, ky = i / 3, j = i - 3 * ky, buf = i & 1;
+            constexpr int i = decltype(ic)::value, ky = i / NG, j = i - NG * ky, buf = i & 1;
             const unsigned char* wa = wl + i * 2048 + aoff;
             fa[buf][0] = *(const bf16x8*)(wa);
             fa[buf][1] = *(const bf16x8*)(wa + 1024);
             const unsigned char* b0 = xb + ky * I_ROWB + j * 32;
             bf16x4 lo = *(const bf16x4*)(b0), hi = *(const bf16x4*)(b0 + 8);
             fb[buf][0] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-            lo = *(const bf16x4*)(b0 + I_ROWB);
-            hi = *(const bf16x4*)(b0 + I_ROWB + 8);
+            lo = *(const bf16x4*)(b0 + S * I_ROWB);
+            hi = *(const bf16x4*)(b0 + S * I_ROWB + 8);
             fb[buf][1] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
         };
         frag(std::integral_constant<int, 0>{});
-        static_for<27>([&](auto ic) {
+        static_for<NK>([&](auto ic) {
             constexpr int i = decltype(ic)::value, cur = i & 1;
-            if constexpr (i + 1 < 27) frag(std::integral_constant<int, i + 1>{});
+            if constexpr (i + 1 < NK) frag(std::integral_constant<int, i + 1>{});
             __builtin_amdgcn_sched_barrier(0);
             acc[0][0] = mfma_bf16(fa[cur][0], fb[cur][0], acc[0][0]);
             acc[0][1] = mfma_bf16(fa[cur][0], fb[cur][1], acc[0][1]);
@@ -840,19 +918,21 @@ __global__ __launch_bounds__(NT, 1) void conv9x9_c3to64_bf16_kernel(I9Params p) 
                         v[4 + j] = hi;
                     }
                     const int gy = gy0 + pt;
-                    const bool ok = gy < p.h && okx;
-                    const long o = ((long)(img * p.h + min(gy, p.h - 1)) * p.w_ + min(gx, p.w_ - 1)) * p.cout + cb * 64 + co;
+                    const bool ok = gy < p.oh && okx;
+                    const long o = ((long)(img * p.oh + min(gy, p.oh - 1)) * p.ow + min(gx, p.ow - 1)) * p.cout + cb * 64 + co;
                     bf16x8 mk;
                     if (p.mask) mk = *(const bf16x8*)(p.mask + o);
-                    bf16x8 ov;
+                    bf16x8 ov, zv;
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
                         float u = v[j] + sh[j];
+                        zv[j] = (__bf16)u;
                         u = u >= 0.f ? u : u * al[j];
                         if (p.mask) u = (float)mk[j] > 0.f ? u : u * p.mask_slope;
                         ov[j] = (__bf16)u;
                     }
                     if (ok) *(bf16x8*)(p.y + o) = ov;
+                    if (p.z && ok) *(bf16x8*)(p.z + o) = zv;
                     if (p.chsum && ok) {                             // the values as stored
 #pragma unroll
                         for (int j = 0; j < 8; ++j) csum[mt * 16 + q * 8 + j] += (float)ov[j];
@@ -868,21 +948,22 @@ __global__ __launch_bounds__(NT, 1) void conv9x9_c3to64_bf16_kernel(I9Params p) 
     }
 }
 
-__global__ void pack_first9x9_kernel(const float* __restrict__ w, uint4* __restrict__ out, int cout, int dgrad) {
-    // out[channel block][k-step = ky*3+j][co in block][half] = 8 bf16: (kx = 4j+2*half, RGB0), (kx+1, RGB0)
-    //   dgrad == 0: w is Keras (9,9,3,cout), the forward kernel of a 3 -> cout convolution
-    //   dgrad == 1: w is Keras (9,9,cout,3), the kernel of a cout -> 3 convolution; packed for its DATA GRADIENT
-    //               (a 3 -> cout convolution with the taps flipped):  W'[ky][kx][c][m] = w[8-ky][8-kx][m][c]
+__global__ void pack_first9x9_kernel(const float* __restrict__ w, uint4* __restrict__ out, int cout, int dgrad, int kh, int kw, int ng) {
+    // out[channel block][k-step = ky*ng+j][co in block][half] = 8 bf16: (kx = 4j+2*half, RGB0), (kx+1, RGB0)
+    //   dgrad == 0: w is Keras (kh,kw,3,cout), the forward kernel of a 3 -> cout convolution
+    //   dgrad == 1: w is Keras (kh,kw,cout,3), the kernel of a cout -> 3 convolution; packed for its DATA GRADIENT
+    //               (a 3 -> cout convolution with the taps flipped):  W'[ky][kx][c][m] = w[kh-1-ky][kw-1-kx][m][c]
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (cout >> 6) * 27 * 64 * 2) return;
-    const int h = idx & 1, co = (idx >> 1) & 63, ks = (idx >> 7) % 27, cb = idx / (27 * 128), ky = ks / 3, j = ks - 3 * ky;
+    const int nk = kh * ng;
+    if (idx >= (cout >> 6) * nk * 64 * 2) return;
+    const int h = idx & 1, co = (idx >> 1) & 63, ks = (idx >> 7) % nk, cb = idx / (nk * 128), ky = ks / ng, j = ks - ng * ky;
     const int m = cb * 64 + co;
     bf16x8 v;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         const int kx = 4 * j + 2 * h + (e >> 2), c = e & 3;
         float x = 0.f;
-        if (kx < 9 && c < 3) x = dgrad ? w[(((8 - ky) * 9 + (8 - kx)) * cout + m) * 3 + c] : w[((ky * 9 + kx) * 3 + c) * cout + m];
+        if (kx < kw && c < 3) x = dgrad ? w[(((kh - 1 - ky) * kw + (kw - 1 - kx)) * cout + m) * 3 + c] : w[((ky * kw + kx) * 3 + c) * cout + m];
         v[e] = (__bf16)x;
     }
     out[idx] = __builtin_bit_cast(uint4, v);
@@ -1324,6 +1405,23 @@ __global__ void pack_final9x9_kernel(const float* __restrict__ w, uint4* __restr
 
 }  // namespace
 
+template <int KH, int NG, int S>
+static int launch_conv3ch(I9Params p, hipStream_t stream) {
+    using C = I3Cfg<KH, NG, S>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)conv_c3to64_bf16_kernel<KH, NG, S>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    const int nblk = p.cout / 64;
+    int per = 1024 / nblk;
+    if (per > p.total) per = p.total;
+    conv_c3to64_bf16_kernel<KH, NG, S><<<per * nblk, NT, C::LDS, stream>>>(p);
+    VCG_LAUNCH_CHECK();
+    return VCG_OK;
+}
+
 extern "C" {
 
 int vcg_pack_conv_kernel_bf16(const void* w, int32_t taps, int32_t a, int32_t b, int32_t transpose, int32_t flip, void* out,
@@ -1572,7 +1670,27 @@ int vcg_pack_conv9x9_3ch_bf16(const void* w, int32_t cout, int32_t dgrad, void* 
     VCG_CHECK_PTR(out);
     if (cout <= 0 || cout % 64 != 0) return VCG_E_SHAPE;
     const int total = (cout >> 6) * 27 * 64 * 2;
-    pack_first9x9_kernel<<<(total + 255) / 256, 256, 0, stream>>>((const float*)w, (uint4*)out, cout, dgrad);
+    pack_first9x9_kernel<<<(total + 255) / 256, 256, 0, stream>>>((const float*)w, (uint4*)out, cout, dgrad, 9, 9, 3);
+    VCG_LAUNCH_CHECK();
+    return VCG_OK;
+}
+
+// Conv2D(cout, k, strides s) on 3 input channels, fp32 NCHW frames -> bf16 NHWC (+bias, LeakyReLU): the critics' block 1
+// (model.py:839 3x3 stride 1; PatchGAN 4x4 stride 2).  wfrag: vcg_conv3ch_bf16_wfrag_bytes(kh, cout) bytes from vcg_pack_conv3ch_bf16.
+static bool conv3ch_supported(int kh, int kw, int stride) { return (kh == 4 && kw == 4 && stride == 2) || (kh == 3 && kw == 3 && stride == 1); }
+
+size_t vcg_conv3ch_bf16_wfrag_bytes(int32_t kh, int32_t kw, int32_t cout) {
+    if (kh <= 0 || kw <= 0 || kw > 4 || cout <= 0 || cout % 64) return 0;
+    return (size_t)(cout >> 6) * kh * 64 * 2 * 16;
+}
+
+int vcg_pack_conv3ch_bf16(const void* w, int32_t kh, int32_t kw, int32_t cout, void* out, hipStream_t stream) {
+    VCG_CHECK_PTR(w);
+    VCG_CHECK_PTR(out);
+    if (cout <= 0 || cout % 64 != 0 || kh <= 0 || kw <= 0) return VCG_E_SHAPE;
+    if (kw > 4) return VCG_E_UNSUPPORTED;
+    const int total = (cout >> 6) * kh * 64 * 2;
+    pack_first9x9_kernel<<<(total + 255) / 256, 256, 0, stream>>>((const float*)w, (uint4*)out, cout, 0, kh, kw, 1);
     VCG_LAUNCH_CHECK();
     return VCG_OK;
 }
@@ -1585,7 +1703,7 @@ static int conv9x9_3ch_wgs(const vcg_conv_desc* d, int cout) {          // workg
 }
 
 static int launch_conv9x9_3ch(const vcg_conv_desc* d, int cout, const void* x, const void* wfrag, const void* bias, const void* prelu_alpha,
-                              const void* mask, float mask_slope, void* y, float* chsum, hipStream_t stream) {
+                              const void* mask, float mask_slope, void* y, float* chsum, hipStream_t stream, void* z = nullptr) {
     const int nblk = cout / 64;
     if (cout % 64 != 0 || nblk < 1 || nblk > 8 || (nblk & (nblk - 1))) return VCG_E_UNSUPPORTED;
     I9Params p;
@@ -1595,6 +1713,7 @@ static int launch_conv9x9_3ch(const vcg_conv_desc* d, int cout, const void* x, c
     p.bias = (const float*)bias;
     p.alpha = (const float*)prelu_alpha;
     p.y = (__bf16*)y;
+    p.z = (__bf16*)z;
     p.mask = (const __bf16*)mask;
     p.mask_slope = mask_slope;
     p.n = d->n;
@@ -1604,17 +1723,47 @@ static int launch_conv9x9_3ch(const vcg_conv_desc* d, int cout, const void* x, c
     p.tiles_x = ceil_div(d->w, TC);
     p.tiles_y = ceil_div(d->h, TR);
     p.total = p.n * p.tiles_x * p.tiles_y;
-    const int lds = I_WB + I_XB + 512;
+    p.oh = d->h; p.ow = d->w; p.pad_top = 4; p.pad_left = 4; p.slope = 1.f;
+    using C = I3Cfg<9, 3, 1>;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv9x9_c3to64_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipError_t e = hipFuncSetAttribute((const void*)conv_c3to64_bf16_kernel<9, 3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
     const int per = conv9x9_3ch_wgs(d, cout);
-    conv9x9_c3to64_bf16_kernel<<<per * nblk, NT, lds, stream>>>(p);
+    conv_c3to64_bf16_kernel<9, 3, 1><<<per * nblk, NT, C::LDS, stream>>>(p);
     VCG_LAUNCH_CHECK();
     return VCG_OK;
+}
+
+int vcg_conv3ch_bf16_fwd(const vcg_conv_desc* d, const void* x, const void* wfrag, const void* bias, float lrelu_slope, void* y, hipStream_t stream) {
+    VCG_CHECK_PTR(d);
+    VCG_CHECK_PTR(x);
+    VCG_CHECK_PTR(wfrag);
+    VCG_CHECK_PTR(y);
+    if (d->n <= 0 || d->h <= 0 || d->w <= 0 || d->oh <= 0 || d->ow <= 0 || d->pad_top < 0 || d->pad_left < 0) return VCG_E_SHAPE;
+    if (d->cin != 3 || !conv3ch_supported(d->kh, d->kw, d->stride)) return VCG_E_UNSUPPORTED;
+    const int nblk = d->cout / 64;
+    if (d->cout % 64 != 0 || nblk < 1 || nblk > 8 || (nblk & (nblk - 1))) return VCG_E_UNSUPPORTED;
+    I9Params p;
+    p.chsum = nullptr;
+    p.x = (const float*)x;
+    p.w = (const uint4*)wfrag;
+    p.bias = (const float*)bias;
+    p.alpha = nullptr;
+    p.slope = lrelu_slope;
+    p.y = (__bf16*)y;
+    p.z = nullptr;
+    p.mask = nullptr;
+    p.mask_slope = 0.f;
+    p.n = d->n; p.h = d->h; p.w_ = d->w; p.cout = d->cout;
+    p.oh = d->oh; p.ow = d->ow; p.pad_top = d->pad_top; p.pad_left = d->pad_left;
+    p.tiles_x = ceil_div(d->ow, TC);
+    p.tiles_y = ceil_div(d->oh, TR);
+    p.total = p.n * p.tiles_x * p.tiles_y;
+    if (d->kh == 4) return launch_conv3ch<4, 1, 2>(p, stream);
+    return launch_conv3ch<3, 1, 1>(p, stream);
 }
 
 int vcg_conv9x9_from3_bf16_fwd(const vcg_conv_desc* d, const void* x, const void* wfrag, const void* bias, const void* prelu_alpha,
@@ -1626,6 +1775,36 @@ int vcg_conv9x9_from3_bf16_fwd(const vcg_conv_desc* d, const void* x, const void
     if (d->n <= 0 || d->h <= 0 || d->w <= 0 || d->oh != d->h || d->ow != d->w) return VCG_E_SHAPE;
     if (d->cin != 3 || d->kh != 9 || d->kw != 9 || d->stride != 1 || d->pad_top != 4 || d->pad_left != 4) return VCG_E_UNSUPPORTED;
     return launch_conv9x9_3ch(d, d->cout, x, wfrag, bias, prelu_alpha, nullptr, 0.f, y, nullptr, stream);
+}
+
+static int prelu_bwd_gridx(int hw) { const int t = ceil_div(hw, 64); return t < 128 ? t : 128; }
+
+int vcg_prelu_bwd_nhwc_bf16_records(int n, int hw) {
+    if (n <= 0 || hw <= 0) return VCG_E_SHAPE;
+    return n * prelu_bwd_gridx(hw);
+}
+
+int vcg_prelu_bwd_nhwc_bf16(const void* d1, const void* d2, const void* z, const float* prelu_alpha, int n, int c, int hw, float* dz_nchw,
+                            float* records, hipStream_t stream) {
+    VCG_CHECK_PTR(d1); VCG_CHECK_PTR(z); VCG_CHECK_PTR(prelu_alpha); VCG_CHECK_PTR(dz_nchw); VCG_CHECK_PTR(records);
+    if (n <= 0 || c <= 0 || hw <= 0 || n > 65535) return VCG_E_SHAPE;
+    if (c % 8) return VCG_E_UNSUPPORTED;
+    prelu_bwd_bf16_to_f32_nchw_kernel<<<dim3(prelu_bwd_gridx(hw), n), 256, 0, stream>>>((const __bf16*)d1, (const __bf16*)d2, (const __bf16*)z, prelu_alpha,
+                                                                                     dz_nchw, records, c, hw, ceil_div(hw, 64));
+    VCG_LAUNCH_CHECK();
+    return VCG_OK;
+}
+
+int vcg_conv9x9_from3_bf16_fwd_train(const vcg_conv_desc* d, const void* x, const void* wfrag, const void* bias, const void* prelu_alpha,
+                                     void* y, void* z, hipStream_t stream) {
+    VCG_CHECK_PTR(d);
+    VCG_CHECK_PTR(x);
+    VCG_CHECK_PTR(wfrag);
+    VCG_CHECK_PTR(y);
+    VCG_CHECK_PTR(z);
+    if (d->n <= 0 || d->h <= 0 || d->w <= 0 || d->oh != d->h || d->ow != d->w) return VCG_E_SHAPE;
+    if (d->cin != 3 || d->kh != 9 || d->kw != 9 || d->stride != 1 || d->pad_top != 4 || d->pad_left != 4) return VCG_E_UNSUPPORTED;
+    return launch_conv9x9_3ch(d, d->cout, x, wfrag, bias, prelu_alpha, nullptr, 0.f, y, nullptr, stream, z);
 }
 
 int vcg_conv9x9_to3_bf16_dgrad(const vcg_conv_desc* d, const void* dy, const void* wfrag, const void* y_prev, float lrelu_slope, void* dx,

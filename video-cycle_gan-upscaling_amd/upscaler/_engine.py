@@ -772,7 +772,9 @@ class Conv2DBf16(Conv2D):
                                                           y.data_ptr(), buf.data_ptr(), rt.stream), "vcg_conv2d_nhwc_bf16_fwd_stats[%s]" % self.name)
         return y, (x, None, d), (buf, nrec)
 
-    def backward(self, ctx, dy, need_dx=True, param_grads=True, which=0, dx_residual=None, tag=None):
+    def backward(self, ctx, dy, need_dx=True, param_grads=True, which=0, dx_residual=None, tag=None, input_lrelu_slope=None):
+        """input_lrelu_slope: the layer's input is the OUTPUT of a LeakyReLU with this slope; dx is then multiplied by its derivative, i.e. it
+        is the gradient in front of that activation (the producing layer's backward then needs no activation pass)"""
         rt = self.rt
         x, _, d = ctx
         if param_grads:
@@ -787,8 +789,143 @@ class Conv2DBf16(Conv2D):
         _, wd = self._packed()
         dx = torch.empty_like(x)
         with Timed(rt, tag and tag + "_dgrad"):
-            L.check(rt.lib.vcg_conv2d_nhwc_bf16_dgrad(ctypes.byref(d), dy.data_ptr(), wd.data_ptr(), None, 0.0, dx.data_ptr(), rt.stream),
-                    "vcg_conv2d_nhwc_bf16_dgrad[%s]" % self.name)
+            L.check(rt.lib.vcg_conv2d_nhwc_bf16_dgrad(ctypes.byref(d), dy.data_ptr(), wd.data_ptr(),
+                                                      x.data_ptr() if input_lrelu_slope is not None else None, float(input_lrelu_slope or 0.0),
+                                                      dx.data_ptr(), rt.stream), "vcg_conv2d_nhwc_bf16_dgrad[%s]" % self.name)
+        return dx
+
+
+class InitialConv9x9Bf16(Conv2D):
+    """initial/conv + initial/prelu (model.py:275-276) as the entry into the bf16 layout: Conv2D(64, 9, 'same') + bias + PReLU from the
+    fp32 NCHW frames to bf16 NHWC in one launch (vcg_conv9x9_from3_bf16_fwd[_train]: bf16 copies of frames and kernel as MFMA operands,
+    fp32 accumulation).  In training the value in front of the PReLU is stored too; backward adds the gradients meeting at the output
+    (trunk + long skip, both bf16 NHWC), applies the activation's derivative and the slope gradient in one pass
+    (vcg_prelu_bwd_nhwc_bf16) whose fp32 NCHW result feeds the fp32 weight-gradient kernel (the frames are fp32 NCHW).  Declares the
+    Conv2D's parameters; the PReLU slope belongs to the NormAct layer behind it (same names as the fp32 model)."""
+
+    def __init__(self, name, cin, cout, k):
+        if cin != 3 or cout != 64 or k != 9:
+            raise NotImplementedError("the bf16 initial convolution is instantiated for 9x9, 3 -> 64 channels")
+        super().__init__(name, cin, cout, k)
+        self._wf = None
+        self._pvalid = False
+
+    def refresh(self):
+        super().refresh()
+        self._pvalid = False
+
+    def _packed(self):
+        rt = self.rt
+        if self._wf is None:
+            self._wf = torch.empty(L.FIRST9X9_WFRAG_BYTES, dtype=torch.uint8, device=rt.device)
+        if not self._pvalid:
+            L.check(rt.lib.vcg_pack_first9x9_bf16(self.ps[self.name + "/kernel"].data_ptr(), self._wf.data_ptr(), rt.stream), "vcg_pack_first9x9_bf16")
+            self._pvalid = True
+        return self._wf
+
+    def forward_prelu(self, x, alpha, training, tag=None):
+        """x fp32 NCHW frames, alpha: the PReLU slopes [64] -> (y bf16 NHWC, ctx)"""
+        rt = self.rt
+        n, _, h, w = x.shape
+        d = self.desc(n, h, w)
+        wf = self._packed()
+        y = torch.empty(n, h, w, self.cout, dtype=torch.bfloat16, device=rt.device)
+        bias = self.ps[self.name + "/bias"].data_ptr()
+        with Timed(rt, tag):
+            if training:
+                z = torch.empty_like(y)
+                L.check(rt.lib.vcg_conv9x9_from3_bf16_fwd_train(ctypes.byref(d), x.data_ptr(), wf.data_ptr(), bias, alpha.data_ptr(), y.data_ptr(),
+                                                                z.data_ptr(), rt.stream), "vcg_conv9x9_from3_bf16_fwd_train")
+            else:
+                z = None
+                L.check(rt.lib.vcg_conv9x9_from3_bf16_fwd(ctypes.byref(d), x.data_ptr(), wf.data_ptr(), bias, alpha.data_ptr(), y.data_ptr(), rt.stream),
+                        "vcg_conv9x9_from3_bf16_fwd")
+        return y, (x, z, d)
+
+    def backward_prelu(self, ctx, d1, d2, alpha, dalpha, which=0, tag=None):
+        """d1 (+ d2 or None): bf16 NHWC gradients at the PReLU's output; writes the kernel / bias gradients and dalpha [64]"""
+        rt, lib = self.rt, self.rt.lib
+        x, z, d = ctx
+        if z is None:
+            raise RuntimeError("backward through an inference-mode forward")
+        hw = d.h * d.w
+        nrec = lib.vcg_prelu_bwd_nhwc_bf16_records(d.n, hw)
+        L.check(min(nrec, 0), "vcg_prelu_bwd_nhwc_bf16_records")
+        rec = rt.empty(nrec * self.cout)
+        dz = rt.empty(d.n, self.cout, d.h, d.w)
+        L.check(lib.vcg_prelu_bwd_nhwc_bf16(d1.data_ptr(), _ptr(d2), z.data_ptr(), alpha.data_ptr(), d.n, self.cout, hw, dz.data_ptr(),
+                                            rec.data_ptr(), rt.stream), "vcg_prelu_bwd_nhwc_bf16")
+        L.check(lib.vcg_sum_records(rec.data_ptr(), nrec, self.cout, 1.0, dalpha.data_ptr(), rt.stream), "vcg_sum_records[%s]" % self.name)
+        ws, wsn = rt.workspace(lib.vcg_conv2d_wgrad_workspace_bytes(ctypes.byref(d)))
+        with Timed(rt, tag and tag + "_wgrad"):
+            L.check(lib.vcg_conv2d_wgrad(ctypes.byref(d), x.data_ptr(), dz.data_ptr(), self.ps.grad(self.name + "/kernel", which).data_ptr(),
+                                         self.ps.grad(self.name + "/bias", which).data_ptr(), ws, wsn, rt.stream), "vcg_conv2d_wgrad[%s]" % self.name)
+
+
+class FirstConvBf16(Conv2D):
+    """A critic's first layer -- Conv2D on the 3-channel fp32 NCHW frames -- writing bf16 NHWC directly (vcg_conv3ch_bf16_fwd: bf16 copies of
+    frames and kernel as MFMA operands, fp32 accumulation, + bias [+ LeakyReLU]): simple_512 / thin_512 block 1 (3x3 'same', model.py:839;
+    its BatchNormalization follows on bf16) and the PatchGAN's 4x4 stride-2 layer + LeakyReLU(0.2).  backward takes the bf16 NHWC gradient
+    IN FRONT of the activation (the next layer's data gradient applies the LeakyReLU mask: Conv2DBf16.backward(mask=...)), turns it into the
+    fp32 NCHW layout once and runs the fp32 weight / data gradient kernels on the fp32 frames."""
+
+    def __init__(self, name, cin, cout, k, stride=1, padding="same", act=L.ACT_NONE, alpha=0.0):
+        if cin != 3 or cout % 64 or cout > 512 or (k, stride) not in ((3, 1), (4, 2)) or act not in (L.ACT_NONE, L.ACT_LRELU):
+            raise NotImplementedError("FirstConvBf16 serves Conv2D(64m, 3, strides 1) / Conv2D(64m, 4, strides 2) on 3 input channels")
+        super().__init__(name, cin, cout, k, stride, padding, act, alpha)
+        self._wf = None
+        self._pvalid = False
+
+    def refresh(self):
+        super().refresh()
+        self._pvalid = False
+
+    def _packed(self):
+        rt = self.rt
+        if self._wf is None:
+            self._wf = torch.empty(rt.lib.vcg_conv3ch_bf16_wfrag_bytes(self.kh, self.kw, self.cout), dtype=torch.uint8, device=rt.device)
+        if not self._pvalid:
+            L.check(rt.lib.vcg_pack_conv3ch_bf16(self.ps[self.name + "/kernel"].data_ptr(), self.kh, self.kw, self.cout, self._wf.data_ptr(), rt.stream),
+                    "vcg_pack_conv3ch_bf16")
+            self._pvalid = True
+        return self._wf
+
+    def forward(self, x, residual=None, tag=None):
+        rt = self.rt
+        n, _, h, w = x.shape
+        d = self.desc(n, h, w)
+        wf = self._packed()
+        y = torch.empty(n, d.oh, d.ow, self.cout, dtype=torch.bfloat16, device=rt.device)
+        with Timed(rt, tag):
+            L.check(rt.lib.vcg_conv3ch_bf16_fwd(ctypes.byref(d), x.data_ptr(), wf.data_ptr(), self.ps[self.name + "/bias"].data_ptr(),
+                                                float(self.alpha) if self.act == L.ACT_LRELU else 1.0, y.data_ptr(), rt.stream),
+                    "vcg_conv3ch_bf16_fwd[%s]" % self.name)
+        return y, (x, y, d)
+
+    def backward(self, ctx, dz, need_dx=True, param_grads=True, which=0, dx_residual=None, tag=None):
+        """dz: bf16 NHWC gradient in front of the activation"""
+        rt = self.rt
+        x, _, d = ctx
+        dz32 = None
+        if param_grads:
+            dz32 = from_bf16_nhwc(rt, dz)
+            ws, wsn = rt.workspace(rt.lib.vcg_conv2d_wgrad_workspace_bytes(ctypes.byref(d)))
+            with Timed(rt, tag and tag + "_wgrad"):
+                L.check(rt.lib.vcg_conv2d_wgrad(ctypes.byref(d), x.data_ptr(), dz32.data_ptr(), self.ps.grad(self.name + "/kernel", which).data_ptr(),
+                                                self.ps.grad(self.name + "/bias", which).data_ptr(), ws, wsn, rt.stream),
+                        "vcg_conv2d_wgrad[%s]" % self.name)
+        if not need_dx:
+            return None
+        dx = rt.empty(d.n, self.cin, d.h, d.w)
+        need = rt.lib.vcg_conv3ch_bf16_dgrad_workspace_bytes(ctypes.byref(d))
+        ws, wsn = rt.workspace(need)
+        with Timed(rt, tag and tag + "_dgrad"):
+            rc = rt.lib.vcg_conv3ch_bf16_dgrad(ctypes.byref(d), dz.data_ptr(), self.ps[self.name + "/kernel"].data_ptr(), dx.data_ptr(), ws, wsn, rt.stream)
+            if rc == L.E_UNSUPPORTED:       # other pads / channel counts: the fp32 data-gradient kernel on the fp32 copy of dz
+                dz32 = from_bf16_nhwc(rt, dz) if dz32 is None else dz32
+                rc = rt.lib.vcg_conv2d_dgrad(ctypes.byref(d), dz32.data_ptr(), self.ps[self.name + "/kernel"].data_ptr(), self._wt().data_ptr(),
+                                             dx.data_ptr(), None, rt.stream)
+            L.check(rc, "vcg_conv3ch_bf16_dgrad[%s]" % self.name)
         return dx
 
 
@@ -845,6 +982,22 @@ def f32_to_bf16(rt, x):
     return y
 
 
+TAIL_CHUNK_MB = int(os.environ.get("VCG_TAIL_CHUNK_MB", "160"))     # 0: whole-batch launches of the up-sampling block and final/conv
+
+
+def tail_chunk(n, h, w, cout=256):
+    """frames per launch of the up-sampling block and final/conv (h, w: the block's INPUT size).  The tensor between them (model.py:288-291)
+    is 2 cout bytes per output pixel -- 134 MB per 512x512 frame -- and only final/conv reads it in the forward pass: walked one chunk of at
+    most TAIL_CHUNK_MB at a time, final/conv finds its input in the 256 MiB Infinity Cache (MI355X_MICROARCH.md: a table stays resident
+    while table + traffic between two uses fit), and an inference pass that re-uses one chunk buffer overwrites its lines before they age
+    out.  Frames larger than the budget (C4's 1080p) keep the whole-batch launches."""
+    per = 4 * h * w * cout * 2
+    budget = TAIL_CHUNK_MB << 20
+    if TAIL_CHUNK_MB <= 0 or per > budget:
+        return n
+    return max(1, min(n, budget // per))
+
+
 class ConvT3x3Bf16(ConvT2D):
     """upsampling_block (model.py:70-75) with bf16 activations: Conv2DTranspose(3, strides 2) 64 -> 64m + bias + LeakyReLU forward on
     vcg_conv_transpose2d_bf16_fwd (bf16 NHWC in and out).  Backward takes the gradient dz in front of the activation (the bf16 data
@@ -876,11 +1029,12 @@ class ConvT3x3Bf16(ConvT2D):
             self._pvalid = True
         return self._wp, self._wg
 
-    def forward(self, x, tag=None):
+    def forward(self, x, tag=None, out=None):
+        """out: optional preallocated [n, 2h, 2w, cout] bf16 tensor (a slice of a whole-batch tensor when the caller walks the batch in chunks)"""
         rt = self.rt
         n, h, w, _ = x.shape
         wp, _ = self._packed()
-        y = torch.empty(n, 2 * h, 2 * w, self.cout, dtype=torch.bfloat16, device=rt.device)
+        y = out if out is not None else torch.empty(n, 2 * h, 2 * w, self.cout, dtype=torch.bfloat16, device=rt.device)
         d = self.desc(n, h, w)
         ep = L.EpilogueBf16(None, self.ps[self.name + "/bias"].data_ptr(), self.act, float(self.alpha), None, None)
         with Timed(rt, tag):
@@ -953,12 +1107,12 @@ class FinalConv9x9Bf16(Conv2D):
             self._pvalid = True
         return self._wf, self._wd
 
-    def forward(self, x, residual=None, tag=None):
+    def forward(self, x, residual=None, tag=None, out=None):
         rt = self.rt
         n, h, w, _ = x.shape
         wf, _ = self._packed()
         d = self.desc(n, h, w)
-        y = rt.empty(n, 3, h, w)
+        y = out if out is not None else rt.empty(n, 3, h, w)
         with Timed(rt, tag):
             L.check(rt.lib.vcg_conv9x9_to3_bf16_fwd(ctypes.byref(d), x.data_ptr(), wf.data_ptr(), self.ps[self.name + "/bias"].data_ptr(),
                                                     1 if self.act == L.ACT_TANH else 0, y.data_ptr(), rt.stream), "vcg_conv9x9_to3_bf16_fwd")

@@ -19,6 +19,7 @@ accumulation and the epilogue arithmetic fp32; the weights are rounded to bf16 o
 (scale = gamma / sqrt(moving_var + 1e-3), shift = (bias - moving_mean) * scale + beta) are 64-element fp32 vectors
 derived by vcg_axpby + vcg_norm_finalize when the engine is built or refreshed."""
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -100,11 +101,15 @@ class Bf16Generator:
             dev = self.rt.device
             bf = lambda c, hh, ww: torch.empty(n, hh, ww, c, dtype=torch.bfloat16, device=dev)
             self._bufs[key] = {"skip": bf(64, h, w),
-                               "a": bf(64, h, w), "b": bf(64, h, w), "c": bf(64, h, w), "u": bf(256, 2 * h, 2 * w),
+                               "a": bf(64, h, w), "b": bf(64, h, w), "c": bf(64, h, w),
+                               "u": torch.empty(self._tail_chunk(n, h, w), 2 * h, 2 * w, 256, dtype=torch.bfloat16, device=dev),
                                "z": bf(64, h, w) if self.instance else None,
                                "stats": torch.empty(5, n * 64, dtype=torch.float32, device=dev) if self.instance else None,
                                "y": torch.empty(n, 3, 2 * h, 2 * w, dtype=torch.float32, device=dev)}
         return self._bufs[key]
+
+    def _tail_chunk(self, n, h, w):
+        return E.tail_chunk(n, h, w)
 
     def _conv(self, x, w, y, scale, shift, act, alpha, res, n, h, wd):
         rt = self.rt
@@ -155,14 +160,18 @@ class Bf16Generator:
         out = B["a"] if cur is not B["a"] else B["c"]
         self._conv(cur, wp, out, sp, hp, L.ACT_NONE, None, B["skip"], n, h, w)
         wt, bt, slope = self.up
-        dt = L.ConvDesc(n, 64, h, w, 256, 2 * h, 2 * w, 3, 3, 2, 0, 0)
-        ept = L.EpilogueBf16(None, bt.data_ptr(), L.ACT_LRELU, slope, None, None)
-        L.check(rt.lib.vcg_conv_transpose2d_bf16_fwd(ctypes.byref(dt), out.data_ptr(), wt.data_ptr(), B["u"].data_ptr(), ctypes.byref(ept),
-                                                     rt.stream), "vcg_conv_transpose2d_bf16_fwd")
         wf, bf_ = self.final
-        df = L.ConvDesc(n, 256, 2 * h, 2 * w, 3, 2 * h, 2 * w, 9, 9, 1, 4, 4)
-        L.check(rt.lib.vcg_conv9x9_to3_bf16_fwd(ctypes.byref(df), B["u"].data_ptr(), wf.data_ptr(), bf_.data_ptr(), 1, B["y"].data_ptr(),
-                                                rt.stream), "vcg_conv9x9_to3_bf16_fwd")
+        ept = L.EpilogueBf16(None, bt.data_ptr(), L.ACT_LRELU, slope, None, None)
+        u, y = B["u"], B["y"]
+        ch = u.shape[0]
+        for i in range(0, n, ch):
+            c = min(ch, n - i)
+            dt = L.ConvDesc(c, 64, h, w, 256, 2 * h, 2 * w, 3, 3, 2, 0, 0)
+            L.check(rt.lib.vcg_conv_transpose2d_bf16_fwd(ctypes.byref(dt), out[i:i + c].data_ptr(), wt.data_ptr(), u.data_ptr(), ctypes.byref(ept),
+                                                         rt.stream), "vcg_conv_transpose2d_bf16_fwd")
+            df = L.ConvDesc(c, 256, 2 * h, 2 * w, 3, 2 * h, 2 * w, 9, 9, 1, 4, 4)
+            L.check(rt.lib.vcg_conv9x9_to3_bf16_fwd(ctypes.byref(df), u.data_ptr(), wf.data_ptr(), bf_.data_ptr(), 1, y[i:i + c].data_ptr(),
+                                                    rt.stream), "vcg_conv9x9_to3_bf16_fwd")
         return B["y"]
 
     # ---- hipGraph ---------------------------------------------------------------------------------------------

@@ -38,6 +38,7 @@ class EpilogueBf16(ctypes.Structure):
 
 
 STATS_NONE, STATS_BATCH, STATS_INSTANCE = 0, 1, 2
+E_UNSUPPORTED = -3            # VCG_E_UNSUPPORTED
 
 # name -> (restype, argtypes); every symbol include/vcg.h declares
 _P = c_void_p
@@ -113,6 +114,14 @@ SIGNATURES = {
     "vcg_norm_act_bwd_bf16_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "vcg_norm_act_bwd_bf16": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_int, c_float, _P, c_int, _P, _P, _P, _P, _P,
                                       c_size_t, _P]),
+    "vcg_conv3ch_bf16_wfrag_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "vcg_pack_conv3ch_bf16": (c_int, [_P, c_int, c_int, c_int, _P, _P]),
+    "vcg_conv3ch_bf16_fwd": (c_int, [_D, _P, _P, _P, c_float, _P, _P]),
+    "vcg_conv3ch_bf16_dgrad_workspace_bytes": (c_size_t, [_D]),
+    "vcg_conv3ch_bf16_dgrad": (c_int, [_D, _P, _P, _P, _P, c_size_t, _P]),
+    "vcg_conv9x9_from3_bf16_fwd_train": (c_int, [_D, _P, _P, _P, _P, _P, _P, _P]),
+    "vcg_prelu_bwd_nhwc_bf16_records": (c_int, [c_int, c_int]),
+    "vcg_prelu_bwd_nhwc_bf16": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P, _P, _P]),
     "vcg_conv2d_cout1_nhwc_bf16_fwd": (c_int, [_D, _P, _P, _P, _P, _P]),
     "vcg_conv2d_cout1_nhwc_bf16_dgrad": (c_int, [_D, _P, _P, _P, _P]),
     "vcg_conv2d_cout1_nhwc_bf16_wgrad_workspace_bytes": (c_size_t, [_D]),

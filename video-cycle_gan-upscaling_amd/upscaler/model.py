@@ -399,6 +399,12 @@ class VGG19Features(Model):
         return d
 
 
+# A/B switches of the bench scripts ("0" = the fp32 layers on layout-converted copies that the bf16 edge layers replaced)
+INIT_BF16 = os.environ.get("VCG_INIT_BF16", "1") != "0"      # generator: initial/conv + PReLU straight into bf16 NHWC
+HEAD_BF16 = os.environ.get("VCG_HEAD_BF16", "1") != "0"      # PatchGAN: the one-channel last convolution on bf16 NHWC
+FIRST_BF16 = os.environ.get("VCG_FIRST_BF16", "1") != "0"    # critics: block 1 (3 input channels) straight into bf16 NHWC
+
+
 class UpscalerOrig(Model):
     """make_upscaler_orig topology (model.py:267-295)."""
 
@@ -424,7 +430,9 @@ class UpscalerOrig(Model):
         self.factor = 2 ** self.upscale_times
         k = kernel_size
         nrm = {"batch": "batch", "instance": "instance"}[norm]
-        self.c_init = self._add(E.Conv2D("initial/conv", output_image_shape[2], filters, 9))
+        # 'bf16+tail': initial/conv + PReLU write the bf16 NHWC trunk input directly (one launch; E.InitialConv9x9Bf16)
+        self.init_bf16 = bool(self.tail_bf16 and output_image_shape[2] == 3 and INIT_BF16)
+        self.c_init = self._add((E.InitialConv9x9Bf16 if self.init_bf16 else E.Conv2D)("initial/conv", output_image_shape[2], filters, 9))
         self.a_init = self._add(E.NormAct("initial/prelu_op", filters, None, L.ACT_PRELU, prelu_name="initial/prelu"))
         self.blocks = []
         for i in range(res_block_num):
@@ -456,10 +464,13 @@ class UpscalerOrig(Model):
 
     def forward(self, x, training):
         tape = []
-        h, c = self.c_init.forward(x); tape.append(c)
-        h, c = self.a_init.forward(h, training); tape.append(c)
-        if self.trunk_dtype == "bf16":          # the trunk (2*res+1 convolutions, norms, adds) on bf16 NHWC; fp32 outside
-            h = E.to_bf16_nhwc(self.rt, h)
+        if self.init_bf16:
+            h, c = self.c_init.forward_prelu(x, self.ps[self.a_init.prelu_name + "/alpha"], training); tape.extend((c, None))
+        else:
+            h, c = self.c_init.forward(x); tape.append(c)
+            h, c = self.a_init.forward(h, training); tape.append(c)
+            if self.trunk_dtype == "bf16":          # the trunk (2*res+1 convolutions, norms, adds) on bf16 NHWC; fp32 outside
+                h = E.to_bf16_nhwc(self.rt, h)
         skip = h
         bf = self.trunk_dtype == "bf16"
 
@@ -484,6 +495,27 @@ class UpscalerOrig(Model):
         h = conv_norm(self.c_pre, self.n_pre, h, residual=skip)
         if self.trunk_dtype == "bf16" and not self.tail_bf16:
             h = E.from_bf16_nhwc(self.rt, h)
+        if self.tail_bf16 and len(self.ups) == 1:
+            # up-sampling block -> final/conv in chunks of frames small enough for the Infinity Cache (E.tail_chunk): final/conv reads the
+            # 256-channel tensor right after it was written.  Training keeps the whole tensor for the backward pass (each chunk is a slice of
+            # it); predict re-uses one chunk buffer.
+            n, hh, ww, _ = h.shape
+            ch = E.tail_chunk(n, hh, ww, self.ups[0].cout)
+            if ch < n:
+                up = self.ups[0]
+                y = self.rt.empty(n, 3, 2 * hh, 2 * ww)
+                uall = torch.empty(n, 2 * hh, 2 * ww, up.cout, dtype=torch.bfloat16, device=self.rt.device) if training else None
+                for i in range(0, n, ch):
+                    c = min(ch, n - i)
+                    u, _ = up.forward(h[i:i + c], tag="convt", out=uall[i:i + c] if training else None)
+                    self.c_fin.forward(u, tag="final_conv", out=y[i:i + c])
+                    del u
+                if training:
+                    tape.append((h, uall, up.desc(n, hh, ww)))
+                    tape.append((uall, y, self.c_fin.desc(n, 2 * hh, 2 * ww)))
+                else:
+                    tape.extend((None, None))
+                return y, tape
         for u in self.ups:
             h, a = u.forward(h, tag="convt"); tape.append(a)
         h, a = self.c_fin.forward(h, tag="final_conv"); tape.append(a)
@@ -504,7 +536,9 @@ class UpscalerOrig(Model):
             for u in reversed(self.ups):
                 d = u.backward(tape.pop(), d, True, True, which, tag="convt")
         # s = skip + BN(conv(h)):  d flows to both
-        if self.tail_bf16:
+        if self.init_bf16:
+            dskip = d                              # bf16 NHWC: added to the trunk's gradient inside the PReLU-backward pass
+        elif self.tail_bf16:
             dskip = E.from_bf16_nhwc(rt, d)        # the long skip joins the fp32 initial/prelu output
         else:
             dskip = d
@@ -519,6 +553,11 @@ class UpscalerOrig(Model):
             d = n1.backward(tape.pop(), d, True, which)
             d = c1.backward(tape.pop(), d, True, True, which, dx_residual=dres, tag="trunk_conv")
         # d is now dL/d(a_init output) from the trunk; add the long-skip gradient
+        if self.init_bf16:
+            tape.pop()
+            self.c_init.backward_prelu(tape.pop(), d, dskip, self.ps[self.a_init.prelu_name + "/alpha"],
+                                       self.ps.grad(self.a_init.prelu_name + "/alpha", which), which)
+            return None
         if self.trunk_dtype == "bf16":
             d = E.from_bf16_nhwc(rt, d)
         E.axpby(rt, dskip, d, 1.0, 1.0)
@@ -531,9 +570,8 @@ class DiscriminatorStack(Model):
     """Strided-conv critic with Flatten/Dense head: make_discriminator_simple_512 (model.py:836-896) and
     make_discriminator_thin_512 (:901-961).
 
-    ``dtype='bf16'`` (BASELINE.json configs C3/C4): blocks 2..9 -- the stride-2 convolutions that hold 97 % of the critic's
-    FLOPs -- and their BatchNormalization / LeakyReLU keep their activations in bf16 NHWC (Conv2DBf16 / NormActBf16: fp32
-    accumulation, statistics, master weights and gradients); block 1 (3 input channels) and the Dense head stay fp32.  Flatten of
+    ``dtype='bf16'`` (BASELINE.json configs C3/C4): every block keeps its activations in bf16 NHWC (block 1: FirstConvBf16 from the fp32
+    NCHW frames; blocks 2..9: Conv2DBf16; NormActBf16: fp32 accumulation, statistics, master weights and gradients); the Dense head stays fp32.  Flatten of
     the NHWC tensor is its memory order, so entering the head is a flat bf16 -> fp32 conversion."""
 
     def __init__(self, input_shape, filters, activation, seed, name, dtype="fp32", kernel=3, strides=None, padding="same", dense1=1024):
@@ -550,8 +588,9 @@ class DiscriminatorStack(Model):
         for i, f in enumerate(filters):
             n = "discriminator/block_%d" % (i + 1)
             s = strides[i]
-            bf = dtype == "bf16" and i > 0
-            conv = E.Conv2DBf16 if bf else E.Conv2D
+            first_bf = dtype == "bf16" and i == 0 and FIRST_BF16 and cin == 3 and f % 64 == 0 and (kernel, s) == (3, 1)
+            bf = dtype == "bf16" and (i > 0 or first_bf)
+            conv = E.FirstConvBf16 if first_bf else E.Conv2DBf16 if bf else E.Conv2D
             norm = E.NormActBf16 if bf else E.NormAct
             cv = self._add(conv(n + "/Conv2d", cin, f, kernel, s, padding))
             self.convs.append((cv, self._add(norm(n + "/BatchNorm", f, "batch", L.ACT_LRELU, 0.1))))
@@ -559,6 +598,7 @@ class DiscriminatorStack(Model):
             if h < 1 or w < 1:
                 raise ValueError("input %s is too small for %s" % (tuple(input_shape), name))
             cin = f
+        self.first_bf16 = isinstance(self.convs[0][0], E.FirstConvBf16)
         self.flat = (h, w, cin)
         self.d1 = self._add(E.Dense("discriminator/final/Dense_1", h * w * cin, dense1))
         self.b1 = self._add(E.NormAct("discriminator/final/BatchNorm_1", dense1, "batch", L.ACT_LRELU, 0.1))
@@ -582,7 +622,7 @@ class DiscriminatorStack(Model):
         tape = []
         h = x
         for i, (cv, na) in enumerate(self.convs):
-            if bf and i == 1:
+            if bf and i == 1 and not self.first_bf16:
                 h = E.to_bf16_nhwc(rt, h)
             if bf and i > 0 and na.needs_stats(training):
                 h, a, st = cv.forward_stats(h, False, tag="d_conv"); tape.append(a)
@@ -627,20 +667,17 @@ class DiscriminatorStack(Model):
         for i, (cv, na) in reversed(list(enumerate(self.convs))):
             d = na.backward(tape.pop(), d, param_grads, which)
             d = cv.backward(tape.pop(), d, need_dx or i > 0, param_grads, which, tag="d_conv")
-            if bf and i == 1:
+            if bf and i == 1 and not self.first_bf16:
                 d = E.from_bf16_nhwc(rt, d)
         return d
-
-
-HEAD_BF16 = os.environ.get("VCG_HEAD_BF16", "1") != "0"      # A/B switch (bench scripts): "0" = the fp32 head on layout-converted copies
 
 
 class DiscriminatorPatchGAN(Model):
     """70x70 PatchGAN (north_star extension): C64-C128-C256 (k4 s2),
     C512 (k4 s1), C1 (k4 s1), zero padding 1, LeakyReLU 0.2, instance (default) or batch norm on the
     three middle blocks.  ``dtype='bf16'``: the three middle blocks (99 % of its FLOPs) on bf16 NHWC activations
-    (Conv2DBf16 / NormActBf16), the 1-channel last convolution reads them as they are (ConvCout1Bf16: fp32 weights and output); the
-    3-channel first convolution is fp32."""
+    (Conv2DBf16 / NormActBf16), the 1-channel last convolution reads them as they are (ConvCout1Bf16: fp32 weights and output), the
+    3-channel first convolution + LeakyReLU writes them from the fp32 NCHW frames (FirstConvBf16)."""
     SPEC = ((64, 2, False), (128, 2, True), (256, 2, True), (512, 1, True), (1, 1, False))
 
     def __init__(self, input_shape, activation, norm, seed, dtype="fp32"):
@@ -659,6 +696,9 @@ class DiscriminatorPatchGAN(Model):
                 bf = dtype == "bf16"
                 cv = self._add((E.Conv2DBf16 if bf else E.Conv2D)(n + "/Conv2d", cin, f, 4, s, 1))
                 na = self._add((E.NormActBf16 if bf else E.NormAct)(n + "/BatchNorm", f, norm, L.ACT_LRELU, 0.2))
+            elif i == 0 and dtype == "bf16" and FIRST_BF16 and cin == 3:
+                cv = self._add(E.FirstConvBf16(n + "/Conv2d", cin, f, 4, s, 1, L.ACT_LRELU, 0.2))   # fp32 NCHW frames -> bf16 NHWC in one launch
+                na = None
             elif last and dtype == "bf16" and HEAD_BF16:
                 cv = self._add(E.ConvCout1Bf16(n + "/Conv2d", cin, f, 4, s, 1))         # reads / writes the bf16 NHWC tensor directly
                 na = None
@@ -667,6 +707,7 @@ class DiscriminatorPatchGAN(Model):
                 na = None
             self.convs.append((cv, na))
             cin = f
+        self.first_bf16 = isinstance(self.convs[0][0], E.FirstConvBf16)
         self._finish()
 
     def _out_shape(self, s):
@@ -681,7 +722,7 @@ class DiscriminatorPatchGAN(Model):
         h = x
         last = len(self.convs) - 1
         for i, (cv, na) in enumerate(self.convs):
-            if bf and i == 1:
+            if bf and i == 1 and not self.first_bf16:
                 h = E.to_bf16_nhwc(rt, h)
             if bf and i == last and not isinstance(cv, E.ConvCout1Bf16):
                 h = E.from_bf16_nhwc(rt, h)
@@ -707,10 +748,14 @@ class DiscriminatorPatchGAN(Model):
         for i, (cv, na) in reversed(list(enumerate(self.convs))):
             if na is not None:
                 d = na.backward(tape.pop(), d, param_grads, which)
-            d = cv.backward(tape.pop(), d, need_dx or i > 0, param_grads, which, tag="d_conv")
+            if bf and i == 1 and self.first_bf16:
+                # block 2's data gradient applies the derivative of block 1's LeakyReLU (its input IS that activation's output)
+                d = cv.backward(tape.pop(), d, True, param_grads, which, tag="d_conv", input_lrelu_slope=self.convs[0][0].alpha)
+            else:
+                d = cv.backward(tape.pop(), d, need_dx or i > 0, param_grads, which, tag="d_conv")
             if bf and i == last and not isinstance(cv, E.ConvCout1Bf16):
                 d = E.to_bf16_nhwc(rt, d)
-            if bf and i == 1:
+            if bf and i == 1 and not self.first_bf16:
                 d = E.from_bf16_nhwc(rt, d)
         return d
 
