@@ -111,6 +111,9 @@ int vcg_sum_records(const float* part, int nrec, int c, float scale, float* out,
  * scale = gamma * rsqrt(moving_var + eps), shift = (bias - moving_mean) * scale + beta; bias / gamma / beta may be NULL (0 / 1 / 0) */
 int vcg_bn_fold(const float* bias, const float* moving_mean, const float* moving_var, const float* gamma, const float* beta, int c, float eps,
                 float* scale, float* shift, vcg_stream_t stream);
+/* the same for `count` (<= 48) pairs in one launch: HOST arrays of device pointers (bias / gamma / beta entries may be NULL); scale, shift [count][c] */
+int vcg_bn_fold_batch(const float* const* bias, const float* const* moving_mean, const float* const* moving_var, const float* const* gamma,
+                      const float* const* beta, int count, int c, float eps, float* scale, float* shift, vcg_stream_t stream);
 /* the same from partial records written by a convolution's epilogue (vcg_epilogue_bf16.stats, vcg_conv2d_nhwc_bf16_fwd_stats):
  * part fp32 [groups][nrec][2][c] = per-record sums and sums of squares over `count` values per group and channel in all; groups = 1
  * (batch statistics; only then are the moving averages updated) or n (instance norm).  Writes mean, scale, shift, invstd [groups*c].
@@ -274,6 +277,10 @@ typedef struct vcg_epilogue_bf16 {
 int vcg_pack_conv_kernel_bf16(const void* w, int32_t taps, int32_t a, int32_t b, int32_t transpose, int32_t flip, void* out,
                               hipStream_t stream);
 
+/* all 3x3 64 -> 64 kernels of a model in one launch: w_host_array = HOST array of `count` (<= 48) device pointers to Keras (3,3,64,64) fp32
+ * kernels; out[count][2][9][64][64] bf16: [i][0] = vcg_pack_conv_kernel_bf16(w_i, 9, 64, 64, transpose 1, flip 0) (forward),
+ * [i][1] = (..., transpose 0, flip 1) (data gradient).  The pointers are read at call time (hipGraph-capturable). */
+int vcg_pack_conv3x3_c64_bf16_batch(const void* const* w_host_array, int32_t count, void* out, hipStream_t stream);
 /* layout + precision change at the edge of the bf16 path */
 int vcg_f32_nchw_to_bf16_nhwc(const void* x, void* y, int32_t n, int32_t c, int32_t h, int32_t w, hipStream_t stream);
 int vcg_bf16_nhwc_to_f32_nchw(const void* x, void* y, int32_t n, int32_t c, int32_t h, int32_t w, hipStream_t stream);

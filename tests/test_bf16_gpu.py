@@ -338,7 +338,7 @@ def test_bf16_generator_instance_norm(rt):
     got = G.to_inference_bf16().predict(x)
     e = rel_err(got, ref.numpy())
     report("bf16 generator (instance norm) predict res=%d n=%d %dx%d  err=%.2e" % (res, n, h, w, e))
-    assert e < 3e-2
+    assert e < 3e-2                                 # observed 1.3e-2 (per-image statistics are re-derived from bf16-stored tensors)
 
 
 @pytest.mark.parametrize("n,h,w", [(1, 8, 32), (2, 16, 64), (1, 13, 45), (3, 40, 72), (2, 5, 7)])
@@ -516,7 +516,7 @@ def test_bf16_generator_at_c4_frame_size(rt):
         hi = 32 if r0 == h - 32 else 18                          # true frame edge, where both pad with zeros)
         e = rel_err(got[:, 2 * (r0 + lo):2 * (r0 + hi)], ref[:, 2 * lo:2 * hi].numpy())
         report("bf16 generator at 540x960->1080x1920, LR rows %d..%d: err=%.2e" % (r0 + lo, r0 + hi, e))
-        assert e < 3e-2
+        assert e < 2e-2                             # observed 5.2e-3 .. 6.2e-3 (2 blocks + tail)
 
 
 @pytest.mark.parametrize("n,h,w,mask", [(1, 12, 32, False), (2, 37, 70, True), (1, 5, 9, True)])
@@ -781,7 +781,9 @@ def test_bf16_discriminator_forward_and_gradients(rt, kind):
     numerically-zero gradients excluded and reported)."""
     from oracle import models as M
     from upscaler import model as PM, _engine as E
-    n, hw = 4, 64
+    # the Dense-head critics halve the map eight times: at 64x64 their last three blocks are BatchNormalizations over n values on 1x1 maps,
+    # which makes ANY fp32 evaluation chaotic (the fp32 oracle itself was 25-60 % off its fp64 run at n = 4): 16 frames of 128x128 for them
+    n, hw = (4, 64) if kind == "patch" else (16, 128)
     if kind == "patch":
         D = PM.make_discriminator_patchgan_70((hw, hw, 3), dtype="bf16")
         dfw = lambda w, x, b: M.discriminator_patchgan_70_forward(w, x, True, bf16=b)[0]
@@ -901,9 +903,9 @@ def test_all_bf16_train_step_at_c4_frame_size(rt):
     report("C4 frame size, all-bf16 step: losses %s (fp32 product %s)  band parity of predict vs fp64 oracle err=%.2e"
            % (["%.5g" % v for v in lb], ["%.5g" % v for v in lf], e))
     assert all(np.isfinite(v) for v in lb)
-    assert e < 2e-2                                # bf16 storage through 2 blocks + tail (3e-2 bound of the 9-block inference test)
+    assert e < 1e-2                                # bf16 storage through 2 blocks + tail: observed 3.1e-3
     for a, b in zip(lb, lf):
-        assert abs(a - b) < 3e-2 * (max(abs(v) for v in lf) + 1e-6), (lb, lf)
+        assert abs(a - b) < 2e-2 * (max(abs(v) for v in lf) + 1e-6), (lb, lf)      # observed 6.5e-3 (adversarial term)
 
 
 # ---------------------------------------------------------------------------------------------------------------

@@ -232,9 +232,9 @@ def test_train_step_parity(rt, wiring, losses, disc, k, d_act, l_act):
     # every weight: the UPDATE (after - before) against the fp64 oracle's update, relative to the largest
     # update of that model.  Gradients such as dgamma = sum(dz * xhat) cancel heavily and carry activation
     # masks, so their fp32 error is percent-level in ANY fp32 implementation: the fp32 run of the oracle
-    # sets the scale (bound: 1e-2, or 4x the fp32 oracle's own error for that tensor).  The two fp32 runs differ
+    # sets the scale (bound: 5e-3, or 2x the fp32 oracle's own error for that tensor).  The two fp32 runs differ
     # only in summation order, and their errors on one tensor scatter by ~10x around each other (the kernels
-    # themselves are checked at 1e-6 on these very shapes in test_kernels_gpu.py), hence the 1e-2 floor.
+    # themselves are checked at 1e-6 on these very shapes in test_kernels_gpu.py), hence the floor.
     worst_stat = 0.0
     for model, ow, ow32, w0, mtag in ((G, orc.g_w, orc32.g_w, g0, "G"), (D, orc.d_w, orc32.d_w, d0, "D")):
         got_w = model.get_weights_dict()
@@ -249,7 +249,7 @@ def test_train_step_parity(rt, wiring, losses, disc, k, d_act, l_act):
             e = float(np.max(np.abs(a - b)) / upd_scale)
             e32 = float(np.max(np.abs(ow32[name].detach().double().numpy() - b)) / upd_scale)
             worst, worst32 = max(worst, e), max(worst32, e32)
-            assert e < max(1e-2, 4 * e32), (mtag, name, e, e32)
+            assert e < max(5e-3, 2 * e32), (mtag, name, e, e32)        # observed: G 0.95e-2 .. 2.3e-2 = 1.0 x e32; D 0.4e-3 .. 4.3e-3 <= e32
         report("train_step %s after: %s max update=%.2e worst update err=%.2e (oracle-fp32 %.2e)" % (tag, mtag, upd_scale, worst, worst32))
     report("train_step %s after: moving-stat err=%.2e" % (tag, worst_stat))
     assert worst_stat < TOL
@@ -273,7 +273,7 @@ def test_train_step_default_adam_vs_fp32_oracle(rt):
             report("default-adam it=%d loss_%s got=%.6g ref=%.6g err=%.1e (oracle-fp32 err=%.1e)" % (it, name, a, b, err, e32))
             if it == 0 and name != "adv":
                 assert err < TOL
-            assert err < max(1e-2, 5 * e32), (name, a, b, c)
+            assert err < max(1e-2, 2.5 * e32), (name, a, b, c)     # observed second iteration: 1.6 x e32 (loss_disc), <= e32 elsewhere
     worst_w = 0.0
     for model, ow in ((G, orc.g_w), (D, orc.d_w)):
         got_w = model.get_weights_dict()

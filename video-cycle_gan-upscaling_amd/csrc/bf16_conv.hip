@@ -59,6 +59,24 @@ __global__ void pack_kernel_bf16(const float* __restrict__ w, __bf16* __restrict
     }
 }
 
+// Every 3x3 64 -> 64 kernel of a model in ONE launch (the trunk re-derives 2 x 19 bf16 copies after each optimizer step: 38 launches of
+// 4.7 us otherwise): blockIdx.y = layer, out[layer][0] = forward pack [tap][co][ci], out[layer][1] = data-gradient pack [8 - tap][ci][co].
+constexpr int PACK_BATCH_MAX = 48;
+struct PackBatch {
+    const float* w[PACK_BATCH_MAX];
+};
+__global__ void pack3x3_c64_batch_kernel(PackBatch pb, __bf16* __restrict__ out) {
+    const float* w = pb.w[blockIdx.y];
+    __bf16* o = out + (long)blockIdx.y * 2 * 9 * 64 * 64;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < 2 * 9 * 64 * 64; idx += gridDim.x * blockDim.x) {
+        const int which = idx / (9 * 64 * 64), r = idx - which * 9 * 64 * 64;
+        const int j = r & 63, i = (r >> 6) & 63, t = r >> 12;
+        // Keras (3,3,in,out): w[tap][ci][co].  forward: out[t][co=i][ci=j] (transpose); data gradient: out[t][ci=i][co=j] of tap 8 - t (flip)
+        const float v = which == 0 ? w[(t * 64 + j) * 64 + i] : w[((8 - t) * 64 + i) * 64 + j];
+        o[idx] = (__bf16)v;
+    }
+}
+
 __global__ void f32_nchw_to_bf16_nhwc_kernel(const float* __restrict__ x, __bf16* __restrict__ y, int n, int c, int hw) {
     // one block per (n, 64-pixel segment): coalesced reads along pixels, coalesced writes along channels
     __shared__ float tile[64][65];
@@ -785,10 +803,30 @@ struct I9Params {
     float slope;                                        // without alpha: LeakyReLU slope (1 = no activation)
 };
 
+// Diagnostic build only (-DVCG_I9_STAMPS, scripts/micro/i9_stamps.sh): s_memtime sums per wave [MFMA loop, barrier after it, epilogue, barrier
+// after it, tiles, kernel clocks] (compute waves) / [fetch issue, barrier 1, stash, barrier 2, tiles, kernel clocks] (loader waves)
+#ifdef VCG_I9_STAMPS
+__device__ unsigned long long vcg_i9_stamp_sums[512 * 8 * 6];
+#define I9_STAMP(t)                                                                   \
+    do {                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                            \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");     \
+        __builtin_amdgcn_sched_barrier(0);                                            \
+    } while (0)
+#define I9_ADD(sum, a, b) sum += (b) - (a)
+#else
+#define I9_STAMP(t) do { } while (0)
+#define I9_ADD(sum, a, b) do { } while (0)
+#endif
+
 template <int KH, int NG, int S>
 __global__ __launch_bounds__(NT, 1) void conv_c3to64_bf16_kernel(I9Params p) {
     using C = I3Cfg<KH, NG, S>;
     constexpr int I_HC = C::HC, I_ROWB = C::ROWB, I_XB = C::XB, I_WB = C::WB, I_NPIX = C::NPIX, I_NPRE = C::NPRE, NK = C::NK;
+#ifdef VCG_I9_STAMPS
+    unsigned long long s0 = 0, s1 = 0, s2 = 0, s3 = 0, ntl = 0, st0, st1, st2, st3, st4;
+    const unsigned long long k_c0 = __builtin_amdgcn_s_memtime();
+#endif
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* wl = smem;
     unsigned char* xl = smem + I_WB;
@@ -843,11 +881,26 @@ __global__ __launch_bounds__(NT, 1) void conv_c3to64_bf16_kernel(I9Params p) {
         lds_barrier();
         for (; tile < p.total; tile += nwg) {
             const int next = tile + nwg;
+            I9_STAMP(st0);
             if (next < p.total) fetch(next);
+            I9_STAMP(st1);
             lds_barrier();
+            I9_STAMP(st2);
             if (next < p.total) stash();
+            I9_STAMP(st3);
             lds_barrier();
+            I9_STAMP(st4);
+            I9_ADD(s0, st0, st1); I9_ADD(s1, st1, st2); I9_ADD(s2, st2, st3); I9_ADD(s3, st3, st4);
+#ifdef VCG_I9_STAMPS
+            ++ntl;
+#endif
         }
+#ifdef VCG_I9_STAMPS
+        if (lane == 0 && blockIdx.x < 512) {
+            unsigned long long* o = vcg_i9_stamp_sums + (blockIdx.x * 8 + wv) * 6;
+            o[0] = s0, o[1] = s1, o[2] = s2, o[3] = s3, o[4] = ntl, o[5] = __builtin_amdgcn_s_memtime() - k_c0;
+        }
+#endif
         return;
     }
 
@@ -862,6 +915,23 @@ __global__ __launch_bounds__(NT, 1) void conv_c3to64_bf16_kernel(I9Params p) {
         const int txi = tile % p.tiles_x, t2 = tile / p.tiles_x, tyi = t2 % p.tiles_y, img = t2 / p.tiles_y;
         const int gx = txi * TC + r, gy0 = tyi * TR + wv * 2;
         const bool okx = gx < p.ow;
+
+        // the LeakyReLU mask of this wave's 2 x 32 pixels (data gradient in front of an activation): requested here, read in the epilogue --
+        // under the MFMA loop.  (Loaded where it was used, each of the eight 16-byte loads waited out an HBM round trip: 6.6k of a tile's
+        // 21k cycles, profiles/r03_i9_stamps.txt.)
+        bf16x8 mk[2][2][2];
+        if (p.mask) {
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+#pragma unroll
+                    for (int pt = 0; pt < 2; ++pt) {
+                        const int gy = gy0 + pt;
+                        const long o = ((long)(img * p.oh + min(gy, p.oh - 1)) * p.ow + min(gx, p.ow - 1)) * p.cout + cb * 64 + mt * 32 + 16 * q + 8 * hh;
+                        mk[mt][q][pt] = *(const bf16x8*)(p.mask + o);
+                    }
+        }
 
         f32x16 acc[2][2];
 #pragma unroll
@@ -884,6 +954,7 @@ __global__ __launch_bounds__(NT, 1) void conv_c3to64_bf16_kernel(I9Params p) {
             hi = *(const bf16x4*)(b0 + S * I_ROWB + 8);
             fb[buf][1] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
         };
+        I9_STAMP(st0);
         frag(std::integral_constant<int, 0>{});
         static_for<NK>([&](auto ic) {
             constexpr int i = decltype(ic)::value, cur = i & 1;
@@ -895,7 +966,9 @@ __global__ __launch_bounds__(NT, 1) void conv_c3to64_bf16_kernel(I9Params p) {
             acc[1][1] = mfma_bf16(fa[cur][1], fb[cur][1], acc[1][1]);
             __builtin_amdgcn_sched_barrier(0);
         });
+        I9_STAMP(st1);
         lds_barrier();
+        I9_STAMP(st2);
 
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
@@ -920,15 +993,13 @@ __global__ __launch_bounds__(NT, 1) void conv_c3to64_bf16_kernel(I9Params p) {
                     const int gy = gy0 + pt;
                     const bool ok = gy < p.oh && okx;
                     const long o = ((long)(img * p.oh + min(gy, p.oh - 1)) * p.ow + min(gx, p.ow - 1)) * p.cout + cb * 64 + co;
-                    bf16x8 mk;
-                    if (p.mask) mk = *(const bf16x8*)(p.mask + o);
                     bf16x8 ov, zv;
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
                         float u = v[j] + sh[j];
                         zv[j] = (__bf16)u;
                         u = u >= 0.f ? u : u * al[j];
-                        if (p.mask) u = (float)mk[j] > 0.f ? u : u * p.mask_slope;
+                        if (p.mask) u = (float)mk[mt][q][pt][j] > 0.f ? u : u * p.mask_slope;
                         ov[j] = (__bf16)u;
                     }
                     if (ok) *(bf16x8*)(p.y + o) = ov;
@@ -939,8 +1010,20 @@ __global__ __launch_bounds__(NT, 1) void conv_c3to64_bf16_kernel(I9Params p) {
                     }
                 }
             }
+        I9_STAMP(st3);
         lds_barrier();
+        I9_STAMP(st4);
+        I9_ADD(s0, st0, st1); I9_ADD(s1, st1, st2); I9_ADD(s2, st2, st3); I9_ADD(s3, st3, st4);
+#ifdef VCG_I9_STAMPS
+        ++ntl;
+#endif
     }
+#ifdef VCG_I9_STAMPS
+    if (lane == 0 && blockIdx.x < 512) {
+        unsigned long long* o = vcg_i9_stamp_sums + (blockIdx.x * 8 + wv) * 6;
+        o[0] = s0, o[1] = s1, o[2] = s2, o[3] = s3, o[4] = ntl, o[5] = __builtin_amdgcn_s_memtime() - k_c0;
+    }
+#endif
     if (p.chsum) {
         // lane (r, hh) ends up with the sum of value r = [mt][q][j] over the wave's 32 pixel lanes: channel mt*32 + 16q + 8hh + j
         const float t = half_wave_reduce_scatter32(csum, r);
@@ -1436,6 +1519,20 @@ int vcg_pack_conv_kernel_bf16(const void* w, int32_t taps, int32_t a, int32_t b,
     return VCG_OK;
 }
 
+int vcg_pack_conv3x3_c64_bf16_batch(const void* const* w_host_array, int32_t count, void* out, hipStream_t stream) {
+    VCG_CHECK_PTR(w_host_array);
+    VCG_CHECK_PTR(out);
+    if (count <= 0 || count > PACK_BATCH_MAX) return VCG_E_SHAPE;
+    PackBatch pb;
+    for (int i = 0; i < count; ++i) {
+        VCG_CHECK_PTR(w_host_array[i]);
+        pb.w[i] = (const float*)w_host_array[i];
+    }
+    pack3x3_c64_batch_kernel<<<dim3(36, count), 256, 0, stream>>>(pb, (__bf16*)out);
+    VCG_LAUNCH_CHECK();
+    return VCG_OK;
+}
+
 int vcg_f32_nchw_to_bf16_nhwc(const void* x, void* y, int32_t n, int32_t c, int32_t h, int32_t w, hipStream_t stream) {
     VCG_CHECK_PTR(x);
     VCG_CHECK_PTR(y);
@@ -1845,6 +1942,12 @@ int vcg_conv9x9_to3_bf16_dgrad_chsum(const vcg_conv_desc* d, const void* dy, con
 extern "C" int vcg_debug_f9_stamps(unsigned long long* host_out) {
     if (hipDeviceSynchronize() != hipSuccess) return -1;
     return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(vcg_f9_stamp_sums), sizeof(unsigned long long) * 512 * 4 * 8);
+}
+#endif
+#ifdef VCG_I9_STAMPS
+extern "C" int vcg_debug_i9_stamps(unsigned long long* host_out) {
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(vcg_i9_stamp_sums), sizeof(unsigned long long) * 512 * 8 * 6);
 }
 #endif
 #ifdef VCG_V2_STAMPS

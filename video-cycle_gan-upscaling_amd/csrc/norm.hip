@@ -177,6 +177,23 @@ __global__ void bn_fold_kernel(const float* bias, const float* mmean, const floa
     shift[i] = ((bias ? bias[i] : 0.f) - mmean[i]) * sc + (beta ? beta[i] : 0.f);
 }
 
+// the same for every (convolution, BatchNormalization) pair of a model in one launch: blockIdx.y = pair, scale / shift [pair][c]
+constexpr int FOLD_BATCH_MAX = 48;
+struct FoldBatch {
+    const float* bias[FOLD_BATCH_MAX];
+    const float* mmean[FOLD_BATCH_MAX];
+    const float* mvar[FOLD_BATCH_MAX];
+    const float* gamma[FOLD_BATCH_MAX];
+    const float* beta[FOLD_BATCH_MAX];
+};
+__global__ void bn_fold_batch_kernel(FoldBatch fb, int c, float eps, float* scale, float* shift) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, l = blockIdx.y;
+    if (i >= c) return;
+    const float sc = (fb.gamma[l] ? fb.gamma[l][i] : 1.f) * rsqrtf(fb.mvar[l][i] + eps);
+    scale[l * c + i] = sc;
+    shift[l * c + i] = ((fb.bias[l] ? fb.bias[l][i] : 0.f) - fb.mmean[l][i]) * sc + (fb.beta[l] ? fb.beta[l][i] : 0.f);
+}
+
 // mean / biased variance from the partial records a convolution's epilogue wrote (part[group][nrec][2][c]: sums, sums of squares of the
 // stored values), then what finalize_kernel does -- one launch instead of statistics partial + final + finalize.
 // block = (group, 64 channels) x 16 record lanes; a thread sums its records (eight in flight) in double, the 16 lanes combine in a
@@ -453,6 +470,21 @@ int vcg_bn_fold(const float* bias, const float* moving_mean, const float* moving
     if (c <= 0) return VCG_E_SHAPE;
     hipLaunchKernelGGL(bn_fold_kernel, dim3(ceil_div(c, 256)), dim3(256), 0, (hipStream_t)stream, bias, moving_mean, moving_var, gamma, beta, c, eps,
                        scale, shift);
+    VCG_LAUNCH_CHECK();
+    return VCG_OK;
+}
+
+int vcg_bn_fold_batch(const float* const* bias, const float* const* moving_mean, const float* const* moving_var, const float* const* gamma,
+                      const float* const* beta, int count, int c, float eps, float* scale, float* shift, vcg_stream_t stream) {
+    VCG_CHECK_PTR(bias); VCG_CHECK_PTR(moving_mean); VCG_CHECK_PTR(moving_var); VCG_CHECK_PTR(gamma); VCG_CHECK_PTR(beta);
+    VCG_CHECK_PTR(scale); VCG_CHECK_PTR(shift);
+    if (c <= 0 || count <= 0 || count > FOLD_BATCH_MAX) return VCG_E_SHAPE;
+    FoldBatch fb;
+    for (int i = 0; i < count; ++i) {
+        VCG_CHECK_PTR(moving_mean[i]); VCG_CHECK_PTR(moving_var[i]);
+        fb.bias[i] = bias[i]; fb.mmean[i] = moving_mean[i]; fb.mvar[i] = moving_var[i]; fb.gamma[i] = gamma[i]; fb.beta[i] = beta[i];
+    }
+    hipLaunchKernelGGL(bn_fold_batch_kernel, dim3(ceil_div(c, 256), count), dim3(256), 0, (hipStream_t)stream, fb, c, eps, scale, shift);
     VCG_LAUNCH_CHECK();
     return VCG_OK;
 }

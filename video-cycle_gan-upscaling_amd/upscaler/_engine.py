@@ -614,6 +614,7 @@ class Conv3x3Bf16(Layer):
         self.cin, self.cout, self.k = cin, cout, 3
         self._wf = self._wd = None
         self._valid = False
+        self._group = None              # PackGroup3x3: all of a model's 3x3 kernels re-packed in one launch
 
     def declare(self, ps):
         ps.declare(self.name + "/kernel", (3, 3, self.cin, self.cout))
@@ -625,9 +626,14 @@ class Conv3x3Bf16(Layer):
 
     def refresh(self):
         self._valid = False
+        if self._group is not None:
+            self._group.valid = False
 
     def _packed(self):
         rt = self.rt
+        if self._group is not None:
+            self._group.ensure()
+            return self._wf, self._wd
         if self._wf is None:
             self._wf = torch.empty(9, 64, 64, dtype=torch.bfloat16, device=rt.device)
             self._wd = torch.empty(9, 64, 64, dtype=torch.bfloat16, device=rt.device)
@@ -654,16 +660,19 @@ class Conv3x3Bf16(Layer):
             y, d = self._run(x, wf, self.ps[self.name + "/bias"].data_ptr())
         return y, (x, d)
 
-    def forward_folded(self, x, norm, residual=None, tag=None):
+    def forward_folded(self, x, norm, residual=None, tag=None, folded=None):
         """learning phase 0: conv + BatchNormalization (moving statistics) [+ PReLU] [+ Add] in ONE launch -- the normalisation is an
         affine map per channel, folded with the bias into the epilogue's scale / shift (vcg_bn_fold); the pre-normalisation tensor is
-        never stored.  norm: the NormActBf16 behind this convolution (batch norm)."""
+        never stored.  norm: the NormActBf16 behind this convolution (batch norm).  folded: (scale, shift) already derived (fold_batch)."""
         rt, ps = self.rt, self.ps
         n, h, wd, _ = x.shape
-        scale, shift = rt.empty(64), rt.empty(64)
-        L.check(rt.lib.vcg_bn_fold(ps[self.name + "/bias"].data_ptr(), ps[norm.name + "/moving_mean"].data_ptr(),
-                                   ps[norm.name + "/moving_variance"].data_ptr(), ps[norm.name + "/gamma"].data_ptr(),
-                                   ps[norm.name + "/beta"].data_ptr(), 64, BN_EPS, scale.data_ptr(), shift.data_ptr(), rt.stream), "vcg_bn_fold")
+        if folded is not None:
+            scale, shift = folded
+        else:
+            scale, shift = rt.empty(64), rt.empty(64)
+            L.check(rt.lib.vcg_bn_fold(ps[self.name + "/bias"].data_ptr(), ps[norm.name + "/moving_mean"].data_ptr(),
+                                       ps[norm.name + "/moving_variance"].data_ptr(), ps[norm.name + "/gamma"].data_ptr(),
+                                       ps[norm.name + "/beta"].data_ptr(), 64, BN_EPS, scale.data_ptr(), shift.data_ptr(), rt.stream), "vcg_bn_fold")
         wf, _ = self._packed()
         y = torch.empty(n, h, wd, 64, dtype=torch.bfloat16, device=rt.device)
         d = L.ConvDesc(n, 64, h, wd, 64, h, wd, 3, 3, 1, 1, 1)
@@ -707,6 +716,46 @@ class Conv3x3Bf16(Layer):
         with Timed(rt, tag and tag + ("_dgrad_res" if dx_residual is not None else "_dgrad")):
             dx, _ = self._run(dy, wdg, None, dx_residual)
         return dx
+
+
+class PackGroup3x3:
+    """the bf16 operand copies (forward + data-gradient pack) of ALL 3x3 64 -> 64 convolutions of a model, re-derived by one launch
+    (vcg_pack_conv3x3_c64_bf16_batch) the first time any of them is needed after a parameter change -- the trunk's 2 x 19 launches of 4.7 us
+    per optimizer step otherwise"""
+
+    def __init__(self, layers):
+        self.layers = list(layers)
+        self.valid = False
+        self.buf = None
+        for l in self.layers:
+            l._group = self
+
+    def ensure(self):
+        if self.valid:
+            return
+        rt = self.layers[0].rt
+        n = len(self.layers)
+        if self.buf is None:
+            self.buf = torch.empty(n, 2, 9, 64, 64, dtype=torch.bfloat16, device=rt.device)
+            for i, l in enumerate(self.layers):
+                l._wf, l._wd = self.buf[i, 0], self.buf[i, 1]
+        arr = (ctypes.c_void_p * n)(*[l.ps[l.name + "/kernel"].data_ptr() for l in self.layers])
+        L.check(rt.lib.vcg_pack_conv3x3_c64_bf16_batch(arr, n, self.buf.data_ptr(), rt.stream), "vcg_pack_conv3x3_c64_bf16_batch")
+        self.valid = True
+
+
+def fold_batch(rt, pairs):
+    """(scale, shift) [len(pairs)][64] of the (Conv3x3Bf16, NormActBf16) pairs of a learning-phase-0 pass: one vcg_bn_fold_batch launch"""
+    n = len(pairs)
+    out = rt.empty(2, n, 64)
+    col = lambda f: (ctypes.c_void_p * n)(*[f(cv, nm) for cv, nm in pairs])
+    L.check(rt.lib.vcg_bn_fold_batch(col(lambda cv, nm: cv.ps[cv.name + "/bias"].data_ptr()),
+                                     col(lambda cv, nm: cv.ps[nm.name + "/moving_mean"].data_ptr()),
+                                     col(lambda cv, nm: cv.ps[nm.name + "/moving_variance"].data_ptr()),
+                                     col(lambda cv, nm: cv.ps[nm.name + "/gamma"].data_ptr()),
+                                     col(lambda cv, nm: cv.ps[nm.name + "/beta"].data_ptr()), n, 64, BN_EPS, out[0].data_ptr(), out[1].data_ptr(),
+                                     rt.stream), "vcg_bn_fold_batch")
+    return {id(cv): (out[0, i], out[1, i]) for i, (cv, nm) in enumerate(pairs)}
 
 
 class Conv2DBf16(Conv2D):
@@ -982,15 +1031,16 @@ def f32_to_bf16(rt, x):
     return y
 
 
-TAIL_CHUNK_MB = int(os.environ.get("VCG_TAIL_CHUNK_MB", "160"))     # 0: whole-batch launches of the up-sampling block and final/conv
+TAIL_CHUNK_MB = int(os.environ.get("VCG_TAIL_CHUNK_MB", "0"))       # 0 (default): whole-batch launches of the up-sampling block and final/conv
 
 
 def tail_chunk(n, h, w, cout=256):
-    """frames per launch of the up-sampling block and final/conv (h, w: the block's INPUT size).  The tensor between them (model.py:288-291)
-    is 2 cout bytes per output pixel -- 134 MB per 512x512 frame -- and only final/conv reads it in the forward pass: walked one chunk of at
-    most TAIL_CHUNK_MB at a time, final/conv finds its input in the 256 MiB Infinity Cache (MI355X_MICROARCH.md: a table stays resident
-    while table + traffic between two uses fit), and an inference pass that re-uses one chunk buffer overwrites its lines before they age
-    out.  Frames larger than the budget (C4's 1080p) keep the whole-batch launches."""
+    """frames per launch of the up-sampling block and final/conv (h, w: the block's INPUT size) -- an experiment kept behind
+    VCG_TAIL_CHUNK_MB, OFF by default.  The tensor between the two layers (model.py:288-291) is 2 cout bytes per output pixel -- 134 MB per
+    512x512 frame -- and only final/conv reads it in the forward pass: walked one chunk of at most TAIL_CHUNK_MB at a time, final/conv could
+    find its input in the 256 MiB Infinity Cache.  Measured (profiles/r03_tail_chunk_ab.txt): it does not pay -- per-frame launches of the
+    two kernels take 59 + 60 us against 47 + 42 us per frame in the whole-batch launches (too few tiles per launch to fill 256 CUs evenly),
+    C5 4563 against 5149 frames/s, C3's shard 522 against 533."""
     per = 4 * h * w * cout * 2
     budget = TAIL_CHUNK_MB << 20
     if TAIL_CHUNK_MB <= 0 or per > budget:

@@ -114,6 +114,8 @@ SIGNATURES = {
     "vcg_norm_act_bwd_bf16_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "vcg_norm_act_bwd_bf16": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_int, c_float, _P, c_int, _P, _P, _P, _P, _P,
                                       c_size_t, _P]),
+    "vcg_pack_conv3x3_c64_bf16_batch": (c_int, [_P, c_int, _P, _P]),
+    "vcg_bn_fold_batch": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_float, _P, _P, _P]),
     "vcg_conv3ch_bf16_wfrag_bytes": (c_size_t, [c_int, c_int, c_int]),
     "vcg_pack_conv3ch_bf16": (c_int, [_P, c_int, c_int, c_int, _P, _P]),
     "vcg_conv3ch_bf16_fwd": (c_int, [_D, _P, _P, _P, c_float, _P, _P]),

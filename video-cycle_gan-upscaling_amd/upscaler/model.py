@@ -453,6 +453,8 @@ class UpscalerOrig(Model):
             cin = 256                                                                 # 256: model.py:288
         self.c_fin = self._add(E.FinalConv9x9Bf16("final/conv", cin, 3, 9) if self.tail_bf16 else E.Conv2D("final/conv", cin, 3, 9, act=L.ACT_TANH))
         self._finish()
+        if bf and len(self.blocks) * 2 + 1 <= 48:
+            E.PackGroup3x3([c for b in self.blocks for c in (b[0], b[2])] + [self.c_pre])
 
     def _out_shape(self, s):
         return (s[0] * self.factor, s[1] * self.factor, 3)
@@ -473,13 +475,17 @@ class UpscalerOrig(Model):
                 h = E.to_bf16_nhwc(self.rt, h)
         skip = h
         bf = self.trunk_dtype == "bf16"
+        folds = {}
+        if bf and not training and self.n_pre.norm == "batch" and E.FOLD_PREDICT and len(self.blocks) * 2 + 1 <= 48:
+            # every folded BatchNormalization of the pass in one launch
+            folds = E.fold_batch(self.rt, [p for b in self.blocks for p in ((b[0], b[1]), (b[2], b[3]))] + [(self.c_pre, self.n_pre)])
 
         def conv_norm(cv, nm, h, residual=None):
             """conv -> norm[-> act][+ residual]; on the bf16 trunk the convolution's epilogue hands the norm its statistics, and in
             learning phase 0 (predict) the whole group is one launch (BatchNormalization folded into the epilogue)"""
             if bf and not training and nm.norm == "batch" and E.FOLD_PREDICT:
                 tape.extend((None, None))
-                return cv.forward_folded(h, nm, residual=residual, tag="trunk_conv")
+                return cv.forward_folded(h, nm, residual=residual, tag="trunk_conv", folded=folds.get(id(cv)))
             if bf and nm.needs_stats(training):
                 h, a, st = cv.forward_stats(h, nm.norm == "instance", tag="trunk_conv"); tape.append(a)
                 h, a = nm.forward(h, training, residual=residual, stats=st); tape.append(a)
