@@ -69,6 +69,17 @@ def pmc_traffic(kernel, shape_key):
     return None, None
 
 
+def pmc_step_traffic(shape_key):
+    """measured HBM bytes of a WHOLE step at `shape_key` (scripts/pmc_step.sh -> scripts/pmc_step_summary.py --merge), or None"""
+    try:
+        for st in json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get("steps", []):
+            if st["shape"] == shape_key:
+                return st
+    except (OSError, ValueError, KeyError):
+        pass
+    return None
+
+
 def _host_cores():
     """cores this process may actually use: cgroup CPU quota if set, else the affinity mask (a GPU box
     exposes all host cores but grants a share -- 16 per GPU on this pool)"""
@@ -204,6 +215,11 @@ def run_c5(args):
                  "kernel": roof["kernel"] + " (64->64 3x3 trunk convolution, bf16 NHWC, folded BN + PReLU epilogue)",
                  "how": "HIP events around the eager launches of 3 passes run right after the timed graph replays",
                  "residual_variant": line("conv3x3_c64_bf16_kernel", True)})  # conv_post + Add: the v1 kernel, 1.5x the bytes
+    st = pmc_step_traffic(shape_key)
+    if st is not None:
+        tot = st["fetch_bytes_per_step"] + st["write_bytes_per_step"]
+        roof["step"] = {"hbm_bytes_per_batch": tot, "hbm_bytes_per_frame": st["bytes_per_frame"], "achieved_gbs": round(tot / (dt / args.steps) / 1e9, 1),
+                        "frac_of_hbm_peak": round(tot / (dt / args.steps) / 1e9 / PEAK_HBM_GBS, 4), "source": st.get("source")}
     out = {
         "metric": "upscaled frames/s (inference, generator only) at %s" % ("256->512" if (h, w) == (256, 256) else "%dx%d->%dx%d" % (h, w, 2 * h, 2 * w)),
         "value": round(B * args.steps / dt, 1), "unit": "frames/s",
@@ -411,6 +427,15 @@ def main():
                     "achieved": round(tfl, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(tfl / PEAK_F32_MFMA_TFLOPS, 4), "flop_per_launch": flop_per_launch}
         traffic, rec = pmc_traffic(kname, shape_key)
+        st = pmc_step_traffic(shape_key) if bf16 else None
+        if st is not None:
+            # the whole step against HBM: measured bytes of every launch of a step (PMC) / the step's wall time
+            step_s = dt / args.steps
+            roof["step"] = {"hbm_bytes_per_step": st["fetch_bytes_per_step"] + st["write_bytes_per_step"], "hbm_bytes_per_frame": st["bytes_per_frame"],
+                            "algorithmic_gb_per_frame": st.get("algorithmic_gb_per_frame"),
+                            "achieved_gbs": round((st["fetch_bytes_per_step"] + st["write_bytes_per_step"]) / step_s / 1e9, 1),
+                            "frac_of_hbm_peak": round((st["fetch_bytes_per_step"] + st["write_bytes_per_step"]) / step_s / 1e9 / PEAK_HBM_GBS, 4),
+                            "source": st.get("source")}
         roof.update({"traffic": traffic, "traffic_source": rec and rec.get("source"),
                      "algorithmic_bytes": roof.get("bytes_per_launch", 2 * args.batch * h * w * 64 * 4 + k * k * 64 * 64 * 4),
                      "launches_timed": launches, "mean_launch_ms": round(mean_ms, 4), "how": roof_note})

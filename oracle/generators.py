@@ -29,6 +29,7 @@ class Net:
         self.names = set()
         self.upd = OrderedDict()          # moving statistics after the step (learning phase 1)
         self.dtype = torch.float64
+        self.norm = "batch"               # 'instance': bn() is the non-affine instance norm of the north_star extension (no parameters)
 
     # -- names ------------------------------------------------------------------------------------------
     def _name(self, name, cls):
@@ -67,6 +68,8 @@ class Net:
 
     def bn(self, x, name=None):
         n = self._name(name, "batch_normalization")
+        if self.norm == "instance":
+            return K.instancenorm(x)
         c = x.shape[1]
         self._get(n + "/gamma", lambda t: M._bn_w(t, n, c))
         y, mm, mv = K.batchnorm(x, self.w[n + "/gamma"], self.w[n + "/beta"], self.w[n + "/moving_mean"], self.w[n + "/moving_variance"], self.training)
@@ -274,6 +277,25 @@ def upscaler_incep_resnet(net, x_nhwc, filters=64, upscale_factor=4, a_block_typ
     for index in range(int(math.log(upscale_factor, 2))):
         model = upsampling_block(net, model, c_block_kernel, 256, 2, "upscaling/%d/block" % index)
     return torch.tanh(net.conv2d(model, 3, 9, 1, "final/conv")).permute(0, 2, 3, 1)
+
+
+def generator_cyclegan(net, x_nhwc, filters=64, n_downsample=2, res_block_num=9, upscale_factor=1, norm="instance", kernel_size=3):
+    """the north_star's generator shape (no reference counterpart): Conv 9x9 + norm + PReLU; n_downsample x
+    [Conv k s2 doubling the channels + norm + PReLU]; residual blocks (model.py:15-27); (n_downsample + log2 f) x [Conv2DTranspose k s2
+    halving them, not below `filters`, + norm + PReLU]; Conv 9x9 -> 3 + tanh.  [N,h,w,3] -> [N,h*f,w*f,3]"""
+    net.norm = norm
+    m = x_nhwc.permute(0, 3, 1, 2)
+    m = net.prelu(net.bn(net.conv2d(m, filters, 9, 1, "stem/conv"), "stem/norm"), "stem/prelu")
+    ch = filters
+    for i in range(n_downsample):
+        ch *= 2
+        m = net.prelu(net.bn(net.conv2d(m, ch, kernel_size, 2, "down/%d/conv" % i), "down/%d/norm" % i), "down/%d/prelu" % i)
+    for i in range(res_block_num):
+        m = residual_block(net, m, kernel_size, ch, 1, "res_block/%d" % i)
+    for i in range(n_downsample + int(math.log(upscale_factor, 2))):
+        ch = max(ch // 2, filters)
+        m = net.prelu(net.bn(net.conv2d_transpose(m, ch, kernel_size, 2, "up/%d/conv_transp" % i), "up/%d/norm" % i), "up/%d/prelu" % i)
+    return torch.tanh(net.conv2d(m, 3, 9, 1, "head/conv")).permute(0, 2, 3, 1)
 
 
 def init_weights(fn, in_shape, seed, **kw):

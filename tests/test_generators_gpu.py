@@ -141,6 +141,19 @@ def test_incep_resnet_other_block_choices(rt):
     assert e0 < 1e-3
 
 
+@pytest.mark.parametrize("norm,f,n_down,res", [("instance", 1, 2, 3), ("batch", 2, 1, 2)])
+def test_generator_cyclegan_matches_oracle(rt, norm, f, n_down, res):
+    """make_generator_cyclegan -- BASELINE.json north_star's literal generator shape (down-sampling convolutions -> residual blocks ->
+    transposed-convolution up-sampling) -- frame-to-frame with instance norm (256-channel residual blocks
+    at h/4) and as a x2 up-scaler with BatchNormalization: names, parameter count, inference, training forward, every gradient."""
+    from oracle import generators as OG
+    from upscaler import model as PM
+    h, w = 24, 40
+    G = PM.make_generator_cyclegan((h * f, w * f, 3), filters=64, n_downsample=n_down, res_block_num=res, upscale_factor=f, norm=norm, seed=3)
+    _check(rt, "cyclegan generator (%s norm, x%d, %d down, %d blocks)" % (norm, f, n_down, res), G, OG.generator_cyclegan,
+           dict(filters=64, n_downsample=n_down, res_block_num=res, upscale_factor=f, norm=norm), (h, w), (h * f, w * f), 31)
+
+
 def test_dropout_masks_change_every_step_and_vanish_at_inference(rt):
     from upscaler import _engine as E, model as PM
     G = PM.make_upscaler_unetish((44, 60, 3), **U)

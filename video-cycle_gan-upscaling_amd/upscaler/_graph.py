@@ -535,3 +535,40 @@ def make_upscaler_attention(output_image_shape, kernel_size=5, filters=64, upsca
         model = upsampling_block_attention(model, upscaler_input, scale, kernel_size, 128, name="upscaling/" + str(index) + "/block")
     model = conv2d(model, 3, 9, 1, "same", activation="tanh", name="final/conv")
     return build_model(upscaler_input, model, name="upscaler_attention", seed=seed)
+
+
+def make_generator_cyclegan(output_image_shape, filters=64, n_downsample=2, res_block_num=9, upscale_factor=1, norm="instance",
+                            kernel_size=3, seed=7):
+    """BASELINE.json north_star's literal generator shape (SURVEY.md section 8 row a11, "canonical down-sampling CycleGAN generator";
+    the reference itself only ships up-scalers): down-sampling convolutions -> residual blocks -> transposed-convolution up-sampling,
+
+        Conv 9x9 (filters) + norm + PReLU                                   stem   (the reference's own 9x9 ends, model.py:275,290)
+        n_downsample x [Conv k s2 (2x channels) + norm + PReLU]             down   (downsampling_block's stride-2 convolution, model.py:63-68)
+        res_block_num x residual_block (model.py:15-27) at the widest width
+        (n_downsample + log2 upscale_factor) x [Conv2DTranspose k s2 (channels / 2, not below `filters`) + norm + PReLU]   (model.py:70-75)
+        Conv 9x9 (3) + tanh                                                 head
+
+    written on the reference's functional block API.  norm: 'instance' (north_star) or 'batch'; PReLU slopes start at 0 (= ReLU).
+    upscale_factor 1 maps a frame to a frame (CycleGAN); 2 / 4 make it an up-scaler like the reference's."""
+    f = int(upscale_factor)
+    if f < 1 or f & (f - 1):
+        raise ValueError("upscale_factor must be a power of two")
+    in_shape = (output_image_shape[0] // f, output_image_shape[1] // f, output_image_shape[2])
+    if in_shape[0] % (1 << n_downsample) or in_shape[1] % (1 << n_downsample):
+        raise ValueError("input %s is not divisible by 2**n_downsample" % (in_shape,))
+    inp = Input(shape=in_shape, name="stem/input")
+    model = conv2d(inp, filters, 9, 1, "same", name="stem/conv")
+    model = batch_norm_prelu(model, name="stem/norm", prelu_name="stem/prelu", norm=norm)
+    ch = filters
+    for i in range(n_downsample):
+        ch *= 2
+        model = conv2d(model, ch, kernel_size, 2, "same", name="down/%d/conv" % i)
+        model = batch_norm_prelu(model, name="down/%d/norm" % i, prelu_name="down/%d/prelu" % i, norm=norm)
+    for i in range(res_block_num):
+        model = residual_block(model, kernel_size, ch, 1, name="res_block/%d" % i, norm=norm)
+    for i in range(n_downsample + int(math.log(f, 2))):
+        ch = max(ch // 2, filters)
+        model = conv2d_transpose(model, ch, kernel_size, 2, name="up/%d/conv_transp" % i)
+        model = batch_norm_prelu(model, name="up/%d/norm" % i, prelu_name="up/%d/prelu" % i, norm=norm)
+    model = conv2d(model, 3, 9, 1, "same", activation="tanh", name="head/conv")
+    return build_model(inp, model, name="generator_cyclegan", seed=seed)

@@ -1341,7 +1341,7 @@ def compile_training_model(upscaler, loss, optimizer=_DEFAULT_ADAM):
 # functional block API (model.py:15-27, 63-75) -- see _graph.py
 # =================================================================================================
 from ._graph import (Input, activation, add, atanh_scaled, batch_norm, batch_norm_prelu, build_model, concatenate, conv2d,  # noqa: E402,F401
-                     conv2d_transpose, cropping2d, downsampling_block, dropout, leaky_relu, make_upscaler_attention,
+                     conv2d_transpose, cropping2d, downsampling_block, dropout, leaky_relu, make_generator_cyclegan, make_upscaler_attention,
                      make_upscaler_orig_functional, multiply_sigmoid, prelu, residual_block, residual_block_attention, resize_images,
                      upsampling_block, upsampling_block_attention)
 # the other generators train_gan3.py offers behind -gm (model.py:332-363, 505-827) -- see _generators.py
