@@ -81,6 +81,9 @@ class Net:
         n = self._name(name, "p_re_lu")
         c = x.shape[1]
         self._get(n + "/alpha", lambda t: M._prelu_w(t, n, c))
+        if n in self.masks:          # the activation mask of another evaluation (x >= 0 there): the same branch of the function, even for
+            #                          pre-activations within rounding of 0
+            return torch.where(self.masks[n].bool(), x, x * self.w[n + "/alpha"].view(1, -1, 1, 1))
         return K.prelu(x, self.w[n + "/alpha"])
 
     def dropout(self, x, rate, name=None):

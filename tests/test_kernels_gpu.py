@@ -37,6 +37,8 @@ def _standalone(rt, layer, seed=0, scale_bias=True):
 CONV_CASES = [
     # cin, cout, k, stride, padding, n, h, w
     (64, 64, 3, 1, "same", 2, 16, 32),
+    (256, 256, 3, 1, "same", 2, 6, 10),      # make_generator_cyclegan's residual blocks at h/4
+    (128, 256, 3, 2, "same", 2, 12, 20),
     (64, 64, 3, 1, "same", 1, 13, 45),       # ragged tile edges
     (8, 64, 3, 1, "same", 1, 9, 33),
     (64, 128, 3, 2, "same", 2, 16, 32),
@@ -130,7 +132,9 @@ def test_conv2d_fused_activation(rt, act):
 
 
 CONVT_CASES = [(64, 256, 3, 1, 8, 32), (64, 256, 3, 2, 7, 19), (256, 256, 3, 1, 6, 6), (64, 256, 5, 1, 9, 33),
-               (16, 64, 3, 1, 4, 40)]
+               (16, 64, 3, 1, 4, 40),
+               # the up-sampling path of make_generator_cyclegan: channels halve, down to 64 -> 64
+               (64, 64, 3, 2, 24, 40), (128, 64, 3, 2, 12, 20), (256, 128, 3, 2, 6, 10)]
 
 
 @pytest.mark.parametrize("cin,cout,k,n,h,w", CONVT_CASES)
@@ -155,6 +159,7 @@ def test_conv_transpose2d(rt, cin, cout, k, n, h, w):
 
 
 NORM_CASES = [("batch", "prelu", 2, 64, 16, 32, True), ("batch", "none", 3, 64, 7, 9, True),
+              ("instance", "prelu", 2, 256, 6, 10, True), ("instance", "prelu", 2, 256, 6, 10, False),      # make_generator_cyclegan's blocks at h/4
               ("batch", "lrelu", 2, 128, 8, 8, False), ("instance", "lrelu", 2, 128, 12, 12, False),
               ("batch", "lrelu", 8, 1024, 1, 1, False), ("batch", "prelu", 1, 64, 64, 64, True),
               # n*c > 65535 planes: Dense BatchNorm_1 (c = 1024) once D sees >= 64 frames (v1 wiring concatenates real + fake);

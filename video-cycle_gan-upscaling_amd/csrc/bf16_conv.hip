@@ -345,6 +345,13 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_c64_bf16_kernel(C3Params p) {
         // 36 k-steps (9 taps x 4 channel groups of 16)
         bf16x8 fa[2][2], fb[2][2];
         bf16x8 rr[2][2][2];
+        // k-step at which the residual tile is requested: under the last 8 k-steps.  Requesting it at k-step 3 (under 32 k-steps, to cover a
+        // whole HBM round trip) measured SLOWER: 73 against 61 us (data gradient + skip) and 57.6 against 55.6 us at batch 8, 194.5 against 190
+        // at batch 32 -- VCG_RES_AT re-defines it for A/B builds
+#ifndef VCG_RES_AT
+#define VCG_RES_AT 27
+#endif
+        constexpr int RES_AT = VCG_RES_AT;
         auto frag = [&](int i, int buf) {
             const int tap = i >> 2, s = i & 3, dy = tap / 3, dx = tap - 3 * dy;
             const unsigned char* wa = wl + tap * 8192 + aoff[s];
@@ -364,8 +371,8 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_c64_bf16_kernel(C3Params p) {
             acc[1][0] = mfma_bf16(fa[cur][1], fb[cur][0], acc[1][0]);
             acc[1][1] = mfma_bf16(fa[cur][1], fb[cur][1], acc[1][1]);
             __builtin_amdgcn_sched_barrier(0);
-            if (i == 27 && RES) {
-                // the residual tile: requested under the last 8 k-steps, 16 bytes (8 channels) per lane and group
+            if (i == RES_AT && RES) {
+                // the residual tile: requested under the remaining k-steps, 16 bytes (8 channels) per lane and group
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -801,7 +808,24 @@ struct I9Params {
     int n, h, w_, cout, tiles_x, tiles_y, total;        // cout = 64 * nblk; workgroup b serves channel block b % nblk; h, w_: INPUT size
     int oh, ow, pad_top, pad_left;                      // output size and the 'before' pads (9x9 'same': h, w_, 4, 4)
     float slope;                                        // without alpha: LeakyReLU slope (1 = no activation)
+    int xcd_group;                                      // block_and_stream
 };
+
+// Several workgroups write different 128-byte channel blocks of the SAME pixels (cout = 64 nblk): mapped so that the nblk workgroups of one
+// tile stream sit on ONE XCD (workgroups b and b + 8 share an XCD under round-robin placement -- speed only, never correctness) and run side by
+// side, their pieces of a pixel's 128 nblk bytes meet in that XCD's L2 and leave it together.  An experiment (VCG_XCD_GROUP=1), measured
+// neutral: convT 389 vs 387 us, the final-conv data gradient 717 vs 712 us at C3's shard -- the default is the plain b % nblk mapping.
+__device__ __forceinline__ void block_and_stream(int nblk, int xcd_group, int& cb, int& wg) {
+    const int b = blockIdx.x;
+    if (xcd_group && gridDim.x % (8 * nblk) == 0) {
+        const int slot = b >> 3;
+        cb = slot % nblk;
+        wg = (slot / nblk) * 8 + (b & 7);
+    } else {
+        cb = b % nblk;
+        wg = b / nblk;
+    }
+}
 
 // Diagnostic build only (-DVCG_I9_STAMPS, scripts/micro/i9_stamps.sh): s_memtime sums per wave [MFMA loop, barrier after it, epilogue, barrier
 // after it, tiles, kernel clocks] (compute waves) / [fetch issue, barrier 1, stash, barrier 2, tiles, kernel clocks] (loader waves)
@@ -833,7 +857,9 @@ __global__ __launch_bounds__(NT, 1) void conv_c3to64_bf16_kernel(I9Params p) {
     float* prm = (float*)(smem + I_WB + I_XB);       // bias[64], slope[64]
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, hh = lane >> 5;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nblk = p.cout >> 6, cb = blockIdx.x % nblk, wg0 = blockIdx.x / nblk, nwg = gridDim.x / nblk;
+    const int nblk = p.cout >> 6, nwg = gridDim.x / nblk;
+    int cb, wg0;
+    block_and_stream(nblk, p.xcd_group, cb, wg0);
 
     for (int c = tid; c < I_WB / 16; c += NT) ((uint4*)wl)[c] = p.w[(long)cb * (I_WB / 16) + c];
     if (tid < 64) {
@@ -1073,6 +1099,7 @@ struct CTParams {
     __bf16* y;
     int n, h, w_, cout, tiles_x, tiles_y, total;    // total = n * tiles_y * tiles_x (per output-channel block)
     float slope;             // LeakyReLU slope (1 = none)
+    int xcd_group;           // block_and_stream
 };
 
 // k-step tables (compile time): phase-major tap order; ky*3+kx and the halo row / column offset of the tap
@@ -1091,7 +1118,9 @@ __global__ __launch_bounds__(NT, 1) void convt3x3_c64_bf16_kernel(CTParams p) {
     unsigned char* xl = smem + WB;
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, hh = lane >> 5;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nblk = p.cout >> 6, cb = blockIdx.x % nblk, wg = blockIdx.x / nblk, nwg = gridDim.x / nblk;
+    const int nblk = p.cout >> 6, nwg = gridDim.x / nblk;
+    int cb, wg;
+    block_and_stream(nblk, p.xcd_group, cb, wg);
     float* prm = (float*)(smem + WB + TXB);          // bias of this block's 64 channels
     if (tid < 64) prm[tid] = p.shift ? p.shift[cb * 64 + tid] : 0.f;
 
@@ -1505,6 +1534,12 @@ static int launch_conv3ch(I9Params p, hipStream_t stream) {
     return VCG_OK;
 }
 
+static int vcg_xcd_group() {
+    // measured neutral (profiles/r03_xcd_group_ab.txt): off unless VCG_XCD_GROUP=1
+    static const int v = [] { const char* e = getenv("VCG_XCD_GROUP"); return e != nullptr && e[0] == '1' ? 1 : 0; }();
+    return v;
+}
+
 extern "C" {
 
 int vcg_pack_conv_kernel_bf16(const void* w, int32_t taps, int32_t a, int32_t b, int32_t transpose, int32_t flip, void* out,
@@ -1695,6 +1730,7 @@ int vcg_conv_transpose2d_bf16_fwd(const vcg_conv_desc* d, const void* x, const v
     }
     int per = 256 / nblk;                       // workgroups per output-channel block
     if (per > p.total) per = p.total;
+    p.xcd_group = vcg_xcd_group();
     convt3x3_c64_bf16_kernel<<<per * nblk, NT, WB + TXB + 256, stream>>>(p);
     VCG_LAUNCH_CHECK();
     return VCG_OK;
@@ -1821,6 +1857,7 @@ static int launch_conv9x9_3ch(const vcg_conv_desc* d, int cout, const void* x, c
     p.tiles_y = ceil_div(d->h, TR);
     p.total = p.n * p.tiles_x * p.tiles_y;
     p.oh = d->h; p.ow = d->w; p.pad_top = 4; p.pad_left = 4; p.slope = 1.f;
+    p.xcd_group = vcg_xcd_group();
     using C = I3Cfg<9, 3, 1>;
     static bool attr_set = false;
     if (!attr_set) {
@@ -1849,6 +1886,7 @@ int vcg_conv3ch_bf16_fwd(const vcg_conv_desc* d, const void* x, const void* wfra
     p.w = (const uint4*)wfrag;
     p.bias = (const float*)bias;
     p.alpha = nullptr;
+    p.xcd_group = vcg_xcd_group();
     p.slope = lrelu_slope;
     p.y = (__bf16*)y;
     p.z = nullptr;

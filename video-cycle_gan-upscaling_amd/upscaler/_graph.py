@@ -315,6 +315,11 @@ def build_model(inputs, outputs, name="model", seed=7):
             """{Dropout layer name: uint8 NCHW keep-mask of the last training forward} (what a parity check feeds the oracle)"""
             return {g.nodes[i][3]["name"]: t for i, t in tape.items() if g.nodes[i][0] == "dropout" and t is not None}
 
+        def norm_contexts(self, tape):
+            """{layer name: (NormAct layer, its saved forward context)} of the last training forward -- what a parity check needs to hand the
+            oracle the activation masks the device actually used (a pre-activation within fp32 rounding of 0 may fall on either side)"""
+            return {layer.name: (layer, tape[i]) for i, (kind, layer, ins, _) in enumerate(g.nodes) if kind == "norm" and tape.get(i) is not None}
+
         def _out_shape(self, s):
             h, w = s[0], s[1]
             shapes = {0: (h, w)}
