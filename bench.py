@@ -286,6 +286,13 @@ def main():
     rehearsal = os.environ.get("VCG_BENCH_REHEARSAL") == "1"
     torch.cuda.set_device(0 if rehearsal else local_rank)
     group = _dist.init_from_env("gloo" if rehearsal else "nccl") if world > 1 else None
+    if world == 1 and os.environ.get("VCG_BENCH_FORCE_GROUP") == "1":
+        # self-check of the N > 1 code path on one GPU over a REAL (1-rank) RCCL communicator: the multi-graph plan, the asynchronous bucket
+        # all-reduce, the per-collective events and the per-rank gather all run; the record says so (its number is a 1-GPU number)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29577")
+        dist.init_process_group("nccl", rank=0, world_size=1)
+        group = dist.group.WORLD
 
     h = args.lr_size
     w = args.lr_width or h
@@ -458,12 +465,14 @@ def main():
                                       "FUSED step (extension, not the headline): no separate predict pass, 3 G + 9 D forward-equivalents" if args.fused_step
                                       else "faithful 3-call step incl. predict pass"),
                        "global_batch": args.batch * world, "frame": "%dx%d->%dx%d" % (h, w, 2 * h, 2 * w),
-                       "parallelism": "dp%d" % world, "launch": ("hipGraph replay" if world == 1 else "%d hipGraphs per step around the RCCL all-reduces" % len(trainer._graph)) if use_graph else "eager"},
+                       "parallelism": "dp%d" % world, "launch": ("hipGraph replay" if group is None else "%d hipGraphs per step around the RCCL all-reduces" % len(trainer._graph)) if use_graph else "eager"},
             "last_losses": [round(float(v), 6) for v in losses],
             "roofline": roof,
         }
         if dp_info is not None:
             out["data_parallel"] = dp_info
+            if world == 1:
+                out["rehearsal"] = "VCG_BENCH_FORCE_GROUP=1: the data-parallel code path over a 1-rank RCCL communicator on one GPU (self-check, not a scaling measurement)"
             if rehearsal:
                 out["rehearsal"] = "VCG_BENCH_REHEARSAL=1: all ranks on ONE GPU, gloo through the host instead of RCCL -- exercises the launcher / multi-graph / reduction logic; its numbers are NOT a scaling measurement"
         if world == 1 and not args.no_cpu_baseline and args.content == "mse" and w == h:
