@@ -7,6 +7,8 @@
 //   blk512      the same on 512-byte pixels: a workgroup owns ONE 128-byte channel block of the pixels, the other three blocks belong to
 //               other workgroups that run concurrently (convt3x3_c64_bf16_kernel's stores, the 3-channel kernel's mask loads + stores)
 //   row512      512-byte pixels, a wave instruction covers 2 whole pixels (32 lanes x 16 bytes each): full pixels by one wave
+//   blk512s2    blk512 with the lanes on every SECOND pixel, the pixels between written in a later pass of the same wave (the transposed
+//               convolution's column phases)
 // for stores, loads, and loads + stores (read one tensor, write another).  Build + run on the GPU box:
 //   hipcc --offload-arch=gfx950 -O3 scripts/micro/stream_patterns.hip -o /tmp/stream_patterns && /tmp/stream_patterns
 #include <hip/hip_runtime.h>
@@ -15,7 +17,7 @@
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-enum { CONTIG = 0, PIX128 = 1, BLK512 = 2, ROW512 = 3 };
+enum { CONTIG = 0, PIX128 = 1, BLK512 = 2, ROW512 = 3, BLK512S2 = 4 };
 enum { ST = 1, LD = 2 };
 
 // byte offset of (unit u, instruction i, lane l) inside a "chunk" of 4 KiB x ... ; each pattern walks the buffer in units
@@ -30,6 +32,11 @@ __device__ __forceinline__ size_t offset_of(size_t unit, int i, int lane, int bl
         const int r = lane & 31, hh = lane >> 5;
         return unit * 16384 + (size_t)r * 512 + blk * 128 + i * 32 + hh * 16;
     }
+    if (PAT == BLK512S2) {                                                                      // unit = 64 pixels of 512 B: lanes address every
+        const int r = lane & 31, hh = lane >> 5;                                                // SECOND pixel (the transposed convolution's column
+        const int sub = (int)(unit & 1);                                                        // phases): odd units fill in the pixels between
+        return (unit >> 1) * 32768 + (size_t)(2 * r + sub) * 512 + blk * 128 + i * 32 + hh * 16;
+    }
     // ROW512: unit = 8 pixels of 512 B, instruction i covers pixels 2i, 2i+1 entirely
     return unit * 4096 + (size_t)i * 1024 + lane * 16;
 }
@@ -38,8 +45,9 @@ template <int PAT, int MODE>
 __global__ __launch_bounds__(256) void k(const unsigned char* __restrict__ src, unsigned char* __restrict__ dst, size_t units, unsigned* sink) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     // BLK512: workgroup b owns channel block b % 4 and unit stream b / 4 (so the four blocks of a unit are touched by four workgroups)
-    const int blk = PAT == BLK512 ? blockIdx.x & 3 : 0;
-    const size_t w0 = (PAT == BLK512 ? blockIdx.x >> 2 : blockIdx.x) * 4 + wv, nw = (size_t)(PAT == BLK512 ? gridDim.x >> 2 : gridDim.x) * 4;
+    constexpr bool B4 = PAT == BLK512 || PAT == BLK512S2;
+    const int blk = B4 ? blockIdx.x & 3 : 0;
+    const size_t w0 = (B4 ? blockIdx.x >> 2 : blockIdx.x) * 4 + wv, nw = (size_t)(B4 ? gridDim.x >> 2 : gridDim.x) * 4;
     u32x4 acc = {0u, 0u, 0u, 0u};
     for (size_t u = w0; u < units; u += nw) {
         u32x4 v[4];
@@ -62,7 +70,7 @@ __global__ __launch_bounds__(256) void k(const unsigned char* __restrict__ src, 
 template <int PAT, int MODE>
 void run(const char* name, unsigned char* a, unsigned char* b, size_t bytes, int occ, unsigned* sink) {
     // units: CONTIG / PIX128 / ROW512 move 4 KiB per unit; BLK512 moves 4 KiB per (unit, block) of a 16 KiB unit
-    const size_t units = PAT == BLK512 ? bytes / 16384 : bytes / 4096;
+    const size_t units = (PAT == BLK512 || PAT == BLK512S2) ? bytes / 16384 : bytes / 4096;
     const int grid = 256 * occ;
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
@@ -88,11 +96,12 @@ int main() {
     if (hipMalloc(&a, bytes) != hipSuccess || hipMalloc(&b, bytes) != hipSuccess || hipMalloc(&sink, 64) != hipSuccess) return 1;
     hipMemset(a, 1, bytes);
     hipMemset(b, 2, bytes);
-    for (int occ : {1, 2, 4, 8}) {
+    for (int occ : {1, 2}) {
         run<CONTIG, ST>("contig", a, b, bytes, occ, sink);
         run<PIX128, ST>("pix128", a, b, bytes, occ, sink);
         run<BLK512, ST>("blk512", a, b, bytes, occ, sink);
         run<ROW512, ST>("row512", a, b, bytes, occ, sink);
+        run<BLK512S2, ST>("blk512s2", a, b, bytes, occ, sink);
         run<CONTIG, LD>("contig", a, b, bytes, occ, sink);
         run<PIX128, LD>("pix128", a, b, bytes, occ, sink);
         run<BLK512, LD>("blk512", a, b, bytes, occ, sink);

@@ -1112,7 +1112,29 @@ __host__ __device__ constexpr bool ct_first(int t) { return t == 0 || t == 4 || 
 __host__ __device__ constexpr bool ct_last(int t) { return t == 3 || t == 5 || t == 7 || t == 8; }
 
 
+// CT_DEFER (default; -DCT_NO_DEFER builds the immediate-store form for A/B): see the tile loop
+#if !defined(CT_NO_DEFER) && !defined(CT_DEFER)
+#define CT_DEFER
+#endif
+// Diagnostic build only (-DVCG_CT_STAMPS, scripts/micro/ct_stamps.sh): per compute wave, s_memtime sums of [tile body = MFMAs + interleaved
+// phase epilogues, barrier A, barrier B, tiles, kernel clocks]
+#ifdef VCG_CT_STAMPS
+__device__ unsigned long long vcg_ct_stamp_sums[256 * 8 * 5];
+#define CT_STAMP(t)                                                                   \
+    do {                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                            \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");     \
+        __builtin_amdgcn_sched_barrier(0);                                            \
+    } while (0)
+#else
+#define CT_STAMP(t) do { } while (0)
+#endif
+
 __global__ __launch_bounds__(NT, 1) void convt3x3_c64_bf16_kernel(CTParams p) {
+#ifdef VCG_CT_STAMPS
+    unsigned long long cs0 = 0, cs1 = 0, cs2 = 0, cnt = 0, ct0, ct1, ct2, ct3;
+    const unsigned long long ck0 = __builtin_amdgcn_s_memtime();
+#endif
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* wl = smem;
     unsigned char* xl = smem + WB;
@@ -1185,6 +1207,20 @@ __global__ __launch_bounds__(NT, 1) void convt3x3_c64_bf16_kernel(CTParams p) {
     const int ow = 2 * p.w_, oh = 2 * p.h;
     lds_barrier();
 
+#ifdef CT_DEFER
+    // Deferred stores: a phase's eight 16-byte stores per lane are not issued behind its MFMAs but one per k-step under the NEXT phase's MFMAs
+    // (the last phase's under the next tile's first k-steps).  Stamps showed a tile as 6.5 k cycles of MFMA issue + 17-23 k cycles in which the
+    // wave sits in store instructions the memory pipe accepts at ~600 cycles each (all six waves at once, ~4.2 TB/s while it lasts) + 6.3 k at
+    // the barriers, i.e. nothing is being stored during 40 % of the time; spread over the whole tile the stores run under the MFMAs.
+    bf16x8 pend[8];
+    long pbase = 0;
+    unsigned pok = 0;                  // bit 0/1: row gy0 / gy0 + 1 of the pending phase is inside the image (and the column is)
+    const long prow = 2l * (2 * p.w_) * p.cout;                        // two output rows further down
+    auto issue = [&](auto jc) {
+        constexpr int j = decltype(jc)::value, mt = j >> 2, q = (j >> 1) & 1, pt = j & 1;
+        if ((pok >> pt) & 1u) *(bf16x8*)(p.y + pbase + pt * prow + mt * 32 + 16 * q) = pend[j];
+    };
+#endif
     for (int tile = wg; tile < p.total; tile += nwg) {
         const int txi = tile % p.tiles_x, t2 = tile / p.tiles_x, tyi = t2 % p.tiles_y, img = t2 / p.tiles_y;
         const int gx = txi * TC + r, gy0 = tyi * TR + wv * 2;
@@ -1192,6 +1228,7 @@ __global__ __launch_bounds__(NT, 1) void convt3x3_c64_bf16_kernel(CTParams p) {
 
         f32x16 acc[2][2];
         bf16x8 fa[2][2], fb[2][2];
+        CT_STAMP(ct0);
         auto frag = [&](auto ic) {
             constexpr int i = decltype(ic)::value, t = i >> 2, s = i & 3, buf = i & 1;
             const unsigned char* wa = wl + ct_tap(t) * 8192 + aoff[s];
@@ -1216,8 +1253,18 @@ __global__ __launch_bounds__(NT, 1) void convt3x3_c64_bf16_kernel(CTParams p) {
             }
             acc[0][0] = mfma_bf16(fa[cur][0], fb[cur][0], acc[0][0]);
             acc[0][1] = mfma_bf16(fa[cur][0], fb[cur][1], acc[0][1]);
+#ifdef CT_DEFER
+            // the pending phase's stores: phase 0 (16 k-steps) takes one every second k-step, phases 1 and 2 (8 k-steps) one per k-step,
+            // phase 3 (4 k-steps) two
+            if constexpr (i < 16) { if constexpr ((i & 1) == 0) issue(std::integral_constant<int, i / 2>{}); }
+            else if constexpr (i < 32) issue(std::integral_constant<int, (i - 16) & 7>{});
+            else { issue(std::integral_constant<int, 2 * (i - 32)>{}); }
+#endif
             acc[1][0] = mfma_bf16(fa[cur][1], fb[cur][0], acc[1][0]);
             acc[1][1] = mfma_bf16(fa[cur][1], fb[cur][1], acc[1][1]);
+#ifdef CT_DEFER
+            if constexpr (i >= 32) issue(std::integral_constant<int, 2 * (i - 32) + 1>{});
+#endif
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (last) {
                 // this phase's 64 channels x 64 output pixels: LeakyReLU, bf16, 16-byte stores
@@ -1245,16 +1292,41 @@ __global__ __launch_bounds__(NT, 1) void convt3x3_c64_bf16_kernel(CTParams p) {
                                 const float u = b >= 0.f ? b : b * p.slope;
                                 ov[j] = (__bf16)u;
                             }
+#ifdef CT_DEFER
+                            pend[mt * 4 + q * 2 + pt] = ov;
+#else
                             const int gy = gy0 + pt;
                             if (gy < p.h && okx)
                                 *(bf16x8*)(p.y + ((long)(img * oh + 2 * gy + py) * ow + 2 * gx + px) * p.cout + cb * 64 + mt * 32 + 16 * q + 8 * hh) = ov;
+#endif
                         }
+#ifdef CT_DEFER
+                pbase = ((long)(img * oh + 2 * gy0 + py) * ow + 2 * gx + px) * p.cout + cb * 64 + 8 * hh;
+                pok = okx ? ((gy0 < p.h ? 1u : 0u) | (gy0 + 1 < p.h ? 2u : 0u)) : 0u;
+#endif
+#ifndef CT_NO_SCHED
                 __builtin_amdgcn_sched_barrier(0);
+#endif
             }
         });
+        CT_STAMP(ct1);
         lds_barrier();
+        CT_STAMP(ct2);
         lds_barrier();
+        CT_STAMP(ct3);
+#ifdef VCG_CT_STAMPS
+        cs0 += ct1 - ct0, cs1 += ct2 - ct1, cs2 += ct3 - ct2, ++cnt;
+#endif
     }
+#ifdef CT_DEFER
+    static_for<8>([&](auto jc) { issue(jc); });            // the last tile's last phase
+#endif
+#ifdef VCG_CT_STAMPS
+    if (lane == 0 && blockIdx.x < 256) {
+        unsigned long long* o = vcg_ct_stamp_sums + (blockIdx.x * 8 + wv) * 5;
+        o[0] = cs0, o[1] = cs1, o[2] = cs2, o[3] = cnt, o[4] = __builtin_amdgcn_s_memtime() - ck0;
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1980,6 +2052,12 @@ int vcg_conv9x9_to3_bf16_dgrad_chsum(const vcg_conv_desc* d, const void* dy, con
 extern "C" int vcg_debug_f9_stamps(unsigned long long* host_out) {
     if (hipDeviceSynchronize() != hipSuccess) return -1;
     return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(vcg_f9_stamp_sums), sizeof(unsigned long long) * 512 * 4 * 8);
+}
+#endif
+#ifdef VCG_CT_STAMPS
+extern "C" int vcg_debug_ct_stamps(unsigned long long* host_out) {
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(vcg_ct_stamp_sums), sizeof(unsigned long long) * 256 * 8 * 5);
 }
 #endif
 #ifdef VCG_I9_STAMPS
