@@ -9,7 +9,7 @@
 //   * workgroup = one (64 output channels) x (64 input channels) block of dW, ALL taps: wave w keeps taps 2w, 2w+1 (two
 //     [64 co] x [64 ci] blocks = 128 accumulator registers) for the whole launch; ceil(K*K/2) waves (5 / 8);
 //   * persistent over pixel tiles (S = 1: 8 x 16 output pixels, S = 2: 4 x 16); a tile's dy pixels and x halo stream
-//     HBM/L2 -> LDS by global_load_lds, double buffered, out-of-image pixels fetched from a zero page;
+//     HBM/L2 -> LDS by buffer_load ... lds through a ring of three stages (two where three do not fit), out-of-image pixels zero-filled by the descriptor's range check;
 //   * LDS image: 128-byte pixel rows (this block's 64 channels); the two 64-byte halves of a row are swapped when bit 1 of
 //     the pixel's column position is set, so the four consecutive pixels of a transposed read fall into four different
 //     16-bank quarters.  For stride 2 the halo's columns are stored de-interleaved (even columns, then odd ones): the
@@ -64,7 +64,11 @@ struct GwCfg {
     static constexpr int NDMA = (CHUNKS + NTH - 1) / NTH;
     static constexpr int BUF = NDMA * NTH * 16;                 // one stage, padded to whole DMA instructions
     static constexpr int WAVE_FLOATS = 8 * 16 * 64;             // a wave's dump: 8 tiles x 16 registers x 64 lanes
+    static constexpr int NS = 3 * BUF <= 160 * 1024 ? 3 : 2;    // stages: with three, TWO tiles are in flight while one is multiplied
     static_assert(2 * BUF <= 160 * 1024, "stages do not fit the LDS");
+    static_assert(NDMA < 64, "vmcnt is a 6-bit counter");
+    // s_waitcnt vmcnt(NDMA): everything but the youngest stage's pieces has landed (expcnt / lgkmcnt fields left open)
+    static constexpr int WAIT_ONE_BEHIND = (NDMA & 15) | ((NDMA >> 4) << 14) | 0x0F70;
 };
 
 struct GwParams {
@@ -118,49 +122,53 @@ __global__ __launch_bounds__((GwCfg<K, S>::NTH), 1) void gwgrad_bf16_kernel(GwPa
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[a][c][d][e] = 0.f;
 
-    const long xpix = (long)p.cin * 2, dypix = (long)p.cout * 2;              // bytes per pixel in HBM
+    // Staging.  A slot is one 16-byte chunk; a wave's piece of DMA round k is the 64 slots from k*NTH + wv*64, i.e. 8 consecutive stored
+    // pixels of ONE region (the regions start at multiples of 64 slots): whether it is dy or x is wave-uniform.  Everything that depends on
+    // (k, lane) only -- the slot's row / column inside the tile, its byte offset from the tile's first pixel, its chunk swizzle -- is loop
+    // invariant; per tile a slot costs two adds, two range checks and a select.  (The first version decoded every slot per tile from
+    // scratch with 64-bit pointers, per-lane branches and a zero page: ~90 VALU instructions per DMA instruction, 900 per tile against
+    // 32 MFMAs -- the kernel was bound by its own address arithmetic.)  Images sit behind one buffer descriptor each: 32-bit offsets,
+    // out-of-image and padding slots get the out-of-range offset (zero fill by the range check).
+    const int xpix = p.cin * 2, dypix = p.cout * 2;                          // bytes per pixel in HBM
+    const long ximg = (long)p.h * p.w_ * xpix, dyimg = (long)p.oh * p.ow * dypix;
+    const int l3 = lane >> 3, l7 = lane & 7;
     auto dma = [&](int tile, int buf) {
         const int txi = tile % p.tiles_x, t2 = tile / p.tiles_x, tyi = t2 % p.tiles_y, img = t2 / p.tiles_y;
         const int oy0 = tyi * C::TR, ox0 = txi * C::TC;
-        int tid_o = tid;
-        asm volatile("" : "+v"(tid_o));            // keep the slot -> address arithmetic inside the loop (see bf16_wgrad.hip)
+        const int gy0 = oy0 * S - p.pt, gx0 = ox0 * S - p.pl;
+        const vcg_rsrc rdy = make_rsrc(p.dy + img * dyimg, (unsigned long)dyimg), rx = make_rsrc(p.x + img * ximg, (unsigned long)ximg);
+        // byte offsets of the tile's first pixels (the x one may be "negative": it is only used modulo 2^32 under a passed range check)
+        const unsigned dybase = (unsigned)((oy0 * p.ow + ox0) * dypix + cob * 128), xbase = (unsigned)((gy0 * p.w_ + gx0) * xpix + cib * 128);
 #pragma unroll
         for (int k = 0; k < C::NDMA; ++k) {
-            const int s = min(k * C::NTH + tid_o, C::CHUNKS - 1);             // the tail re-fetches the last chunk into its own slot
-            const bool isx = s >= C::DYB / 16;
-            const int sl = isx ? s - C::DYB / 16 : s;
-            const int L = sl >> 3;                                            // stored pixel index inside its region
-            int row, pos;
-            if (isx) { row = L / C::PITCH; pos = L - row * C::PITCH; } else { row = L / C::TC; pos = L - row * C::TC; }
-            const int cs = (sl & 7) ^ (4 * ((pos >> 1) & 1));                 // stored chunk (sl&7) holds source chunk cs
-            int gy, gx;
-            bool ok;
-            if (isx) {
-                const int col = S == 2 ? (pos < C::HALF ? 2 * pos : 2 * (pos - C::HALF) + 1) : pos;
-                gy = oy0 * S - p.pt + row;
-                gx = ox0 * S - p.pl + col;
-                ok = col < C::XC && pos < C::XPOS && (unsigned)gy < (unsigned)p.h && (unsigned)gx < (unsigned)p.w_;
+            const int sb = k * C::NTH + wv * 64;                              // first slot of this wave's piece (scalar)
+            void __attribute__((address_space(3)))* dst = (void __attribute__((address_space(3)))*)(smem + buf * C::BUF + sb * 16);
+            if (sb < C::DYB / 16) {
+                const int m = sb >> 6, row = m / (C::TC / 8), pos = (m % (C::TC / 8)) * 8 + l3;      // TC = 16: a piece is half a tile row
+                const unsigned rel = (unsigned)((row * p.ow + pos) * dypix + ((l7 ^ (4 * ((pos >> 1) & 1))) * 16));
+                const bool ok = oy0 + row < p.oh && ox0 + pos < p.ow;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rdy, dst, 16, ok ? dybase + rel : VCG_OOB, 0, 0, 0);
             } else {
-                gy = oy0 + row;
-                gx = ox0 + pos;
-                ok = (unsigned)gy < (unsigned)p.oh && (unsigned)gx < (unsigned)p.ow;
+                const int L = ((sb - C::DYB / 16) >> 3) + l3, row = L / C::PITCH, pos = L - row * C::PITCH;
+                const int col = S == 2 ? (pos < C::HALF ? 2 * pos : 2 * (pos - C::HALF) + 1) : pos;
+                const unsigned rel = (unsigned)((row * p.w_ + col) * xpix + ((l7 ^ (4 * ((pos >> 1) & 1))) * 16));
+                const bool ok = row < C::XR && col < C::XC && pos < C::XPOS && (unsigned)(gy0 + row) < (unsigned)p.h && (unsigned)(gx0 + col) < (unsigned)p.w_;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, dst, 16, ok ? xbase + rel : VCG_OOB, 0, 0, 0);
             }
-            const unsigned char* src = (const unsigned char*)vcg_zero_word;
-            if (ok) src = isx ? p.x + ((long)(img * p.h + gy) * p.w_ + gx) * xpix + cib * 128 + cs * 16
-                              : p.dy + ((long)(img * p.oh + gy) * p.ow + gx) * dypix + cob * 128 + cs * 16;
-            // lanes of one instruction write consecutive 16-byte slots: slot index = k*NTH + tid
-            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src,
-                                             (void __attribute__((address_space(3)))*)(smem + buf * C::BUF + (k * C::NTH + wv * 64) * 16), 16, 0, 0);
         }
     };
 
+    // ring of NS stages: the pieces of the next NS - 1 tiles are in flight while this one is multiplied (a wave's loads retire in
+    // order, so "at most NDMA outstanding" means this tile's stage is complete)
     int tile = slab, buf = 0;
     if (tile < p.total) dma(tile, 0);
-    for (; tile < p.total; tile += p.slabs, buf ^= 1) {
-        __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0): this wave's part of the stage has landed
-        lds_barrier_g();                             // ... and everyone else's; the other buffer is free again
-        const int next = tile + p.slabs;
-        if (next < p.total) dma(next, buf ^ 1);
+    if (C::NS == 3 && tile + p.slabs < p.total) dma(tile + p.slabs, 1);
+    for (; tile < p.total; tile += p.slabs, buf = buf + 1 == C::NS ? 0 : buf + 1) {
+        if (C::NS == 3 && tile + p.slabs < p.total) __builtin_amdgcn_s_waitcnt(C::WAIT_ONE_BEHIND);
+        else __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0): this wave's part of the stage has landed
+        lds_barrier_g();                             // ... and everyone else's; the stage multiplied last is free again
+        const int next = tile + (C::NS - 1) * p.slabs;
+        if (next < p.total) dma(next, buf == 0 ? C::NS - 1 : buf - 1);
         const unsigned lb = lds0 + buf * C::BUF;
 
         sfor<C::KSTEPS>([&](auto ic) {
@@ -315,9 +323,9 @@ template <int K, int S>
 int launch_gw(const GwParams& p, int grid, hipStream_t st) {
     using C = GwCfg<K, S>;
     auto kern = gwgrad_bf16_kernel<K, S>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * C::BUF);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::NS * C::BUF);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(C::NTH), 2 * C::BUF, st, p);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(C::NTH), C::NS * C::BUF, st, p);
     VCG_LAUNCH_CHECK();
     return VCG_OK;
 }
@@ -328,6 +336,7 @@ int gw_run(const void* x, const void* dy, float* dw, float* db, int n, int h, in
     const GwPlan pl = gw_plan(n, cin, oh, ow, cout, k, s);
     if (!pl.ok) return VCG_E_UNSUPPORTED;
     if (ws == nullptr || ws_bytes < pl.ws_bytes) return VCG_E_WORKSPACE;
+    if ((long)h * w * cin * 2 > 0xFFFFFFE0l || (long)oh * ow * cout * 2 > 0xFFFFFFE0l) return VCG_E_UNSUPPORTED;     // an image behind one buffer descriptor
     GwParams p{};
     p.x = (const unsigned char*)x; p.dy = (const unsigned char*)dy;
     p.ws = (float*)ws; p.wsb = (float*)((char*)ws + pl.ws_part);
