@@ -9,7 +9,7 @@
 // transposed staging pass, and the tap shift is plain address arithmetic on whole pixels (no alignment issue).
 //   * LDS image: 128-byte pixel rows whose two 64-byte halves are swapped when bit 1 of the pixel index is set: the four
 //     consecutive pixels of a transposed read then fall into four different 16-bank quarters (conflict-free);
-//   * persistent workgroups of 6 waves = 3 tap rows x 2 pixel halves of an 8x32-pixel tile; a wave keeps the whole
+//   * persistent workgroups of 6 compute waves = 3 tap rows x 2 pixel halves of an 8x32-pixel tile (+ 2 loader waves); a wave keeps the whole
 //     [64 co] x [3 dx x 64 ci] block of its tap row in 192 accumulator VGPRs for the entire launch (12 MFMAs per
 //     2 + 6 operand fragments);
 //   * tiles stream HBM -> LDS by global_load_lds (double buffered, swizzle applied on the global side, out-of-image
@@ -47,10 +47,11 @@ constexpr int G_R = 8, G_C = 32;                       // output-pixel tile
 constexpr int G_DYB = G_R * G_C * 128;                 // 32768
 constexpr int G_XP = G_C + 2;                          // halo tile pitch (pixels)
 constexpr int G_XB = (G_R + 2) * G_XP * 128;           // 43520
-constexpr int G_NW = 6;
+constexpr int G_NW = 6;                                // compute waves
+constexpr int G_NL = 2, G_NWT = G_NW + G_NL;           // + loader waves (they only issue the tiles' DMA)
 constexpr int G_CHUNKS = (G_DYB + G_XB) / 16;          // 4768 16-byte chunks per stage
-constexpr int G_NDMA = (G_CHUNKS + G_NW * 64 - 1) / (G_NW * 64);      // 13 DMA instructions per lane and stage
-constexpr int G_BUF = G_NDMA * G_NW * 64 * 16;         // one stage, padded to whole DMA instructions (79872 B): the lanes
+constexpr int G_NDMA = (G_CHUNKS + G_NL * 64 - 1) / (G_NL * 64);      // 38 DMA instructions per loader lane and stage
+constexpr int G_BUF = G_NDMA * G_NL * 64 * 16;         // one stage, padded to whole DMA instructions (77824 B): the lanes
                                                        // past the last chunk land in the padding
 constexpr int G_WAVE_FLOATS = 12 * 16 * 64;            // a wave's partial block: 12 tiles x 16 registers x 64 lanes
 
@@ -62,7 +63,25 @@ struct WgParams {
     int n, h, w_, tiles_x, tiles_y, total;
 };
 
-__global__ __launch_bounds__(G_NW * 64, 1) void wgrad3x3_c64_bf16_kernel(WgParams p) {
+// Diagnostic build only (-DVCG_WG_STAMPS, scripts/micro/wg_stamps.sh): per wave, s_memtime sums of [wait for the stage's DMA, barrier, DMA issue,
+// k-steps, tiles, kernel clocks]
+#ifdef VCG_WG_STAMPS
+__device__ unsigned long long vcg_wg_stamp_sums[256 * G_NWT * 6];
+#define WG_STAMP(t)                                                                   \
+    do {                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                            \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");     \
+        __builtin_amdgcn_sched_barrier(0);                                            \
+    } while (0)
+#else
+#define WG_STAMP(t) do { } while (0)
+#endif
+
+__global__ __launch_bounds__(G_NWT * 64, 1) void wgrad3x3_c64_bf16_kernel(WgParams p) {
+#ifdef VCG_WG_STAMPS
+    unsigned long long ws0 = 0, ws1 = 0, ws2 = 0, ws3 = 0, wcnt = 0, wt0, wt1, wt2, wt3, wt4;
+    const unsigned long long wk0 = __builtin_amdgcn_s_memtime();
+#endif
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -99,51 +118,93 @@ __global__ __launch_bounds__(G_NW * 64, 1) void wgrad3x3_c64_bf16_kernel(WgParam
                 for (int e = 0; e < 16; ++e) acc[a][b][c][e] = 0.f;
 
     const long img_bytes = (long)p.h * p.w_ * 128;
-    auto dma = [&](int tile, int buf) {
-        const int txi = tile % p.tiles_x, t2 = tile / p.tiles_x, tyi = t2 % p.tiles_y, img = t2 / p.tiles_y;
-        const int y0 = tyi * G_R, x0 = txi * G_C;
-        // Thirteen 1-KiB pieces per wave and stage.  What the address arithmetic may cost is set by the 96 MFMAs of a tile: round 2
-        // decoded every slot from a spilled copy of threadIdx (a scratch reload + vmcnt(0) per tile) through per-lane branches --
-        // about a thousand instructions per tile.  Here a piece's first slot k*384 + wv*64 is wave-uniform, so dy or x, and for dy the
-        // row, are scalar; the lane id is re-read from mbcnt (no register held across the tile loop); out-of-image pixels get the
-        // out-of-range offset of the image's buffer descriptor (zero fill by the range check: no zero page, no 64-bit lane pointers).
-        const vcg_rsrc rdy = make_rsrc(p.dy + img * img_bytes, (unsigned long)img_bytes), rx = make_rsrc(p.x + img * img_bytes, (unsigned long)img_bytes);
-        int ln = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)), wvo = wv;
-        asm volatile("" : "+v"(ln), "+s"(wvo));        // opaque: hoisted out of the tile loop this arithmetic holds ~40 registers the kernel
-        //                                               does not have (192 are accumulators); a spilled one comes back as a scratch load,
-        //                                               which shares vmcnt with the DMA: every reload waits for the pieces before it
-        const int l3 = ln >> 3, l7 = ln & 7;
-        const unsigned cs16 = (unsigned)((l7 ^ (4 * ((l3 >> 1) & 1))) * 16);       // stored chunk l7 holds source chunk l7 ^ 4*((pixel >> 1) & 1)
+    // Staging belongs to two LOADER waves (wv >= G_NW), 38 1-KiB pieces each per stage.  In-kernel stamps (scripts/micro/wg_stamps.*,
+    // profiles/r03_wg_stamps.txt) of the form in which the six compute waves issued 13 pieces each: 2.6-3.7 k of a tile's 11.2 k ticks in
+    // the issue block behind the barrier (every `buffer_load ... lds` waits for room in the CU's memory pipe; no wave multiplies meanwhile)
+    // and next to nothing waiting for the data afterwards; with the pieces spread over the k-steps the same ticks moved into the k-steps
+    // (an issue that stalls holds up the MFMAs behind it in program order).  A piece's first slot k*128 + lw*64 is wave-uniform, so dy
+    // or x, and for dy the row, are scalar; out-of-image pixels get the out-of-range offset of the image's buffer descriptor (zero fill
+    // by the range check: no zero page, no 64-bit lane pointers).
+    if (wv >= G_NW) {
+        // Loader waves.  Rounds 0..15 carry dy (2048 slots = 16 x 128), rounds 16..37 the x halo: which region a piece belongs to is a
+        // compile-time property of k.  Everything that depends on (k, lane) only is computed ONCE (the loaders have the registers: no
+        // accumulators): for dy the piece is 8 consecutive pixels of row k >> 1, the lane part has two variants (k & 1); for x a lane's
+        // (row, column) of the 10 x 34 halo and its byte offset per round.  Per tile a piece is an add, its range check and a select --
+        // the first loader version re-derived each slot per tile (~30 instructions per piece, 6.2-6.8 k ticks of issue per tile: the
+        // loaders, not the multiplying waves, set the tile time).
+        constexpr int KDY = G_DYB / 16 / (G_NL * 64), NX = G_NDMA - KDY;
+        static_assert(G_DYB / 16 % (G_NL * 64) == 0 && G_C == 32, "wgrad3x3 loaders: dy rounds");
+        const int lw = wv - G_NW, l3 = lane >> 3, l7 = lane & 7;
+        int pdy[2];
+        unsigned rdy[2];
 #pragma unroll
-        for (int k = 0; k < G_NDMA; ++k) {
-            const int sb = k * (G_NW * 64) + wvo * 64;                            // first slot of this wave's piece: a multiple of 64
-            void __attribute__((address_space(3)))* dst = (void __attribute__((address_space(3)))*)(smem + buf * G_BUF + sb * 16);
-            if (sb < G_DYB / 16) {
-                // dy tile [8][32] pixels: the piece is 8 consecutive pixels of ONE row
-                const int m = sb >> 6, gy = y0 + (m >> 2), xb = x0 + (m & 3) * 8;
-                unsigned off = (unsigned)((gy * p.w_ + xb) * 128) + (unsigned)(l3 * 128) + cs16;
-                asm volatile("" : "+v"(off));
-                off = (gy < p.h && xb + l3 < p.w_) ? off : VCG_OOB;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rdy, dst, 16, off, 0, 0, 0);
-            } else {
-                // x halo tile [10][34] pixels: 8 consecutive pixels, possibly across a row end; P / 34 by multiplication (exact below 340)
-                const int P = ((sb - G_DYB / 16) >> 3) + l3, row = (P * 241) >> 13, col = P - row * G_XP;
-                const int gy = y0 + row - 1, gx = x0 + col - 1;
-                unsigned off = (unsigned)((gy * p.w_ + gx) * 128) + cs16;
-                asm volatile("" : "+v"(off));
-                off = ((unsigned)gy < (unsigned)p.h && (unsigned)gx < (unsigned)p.w_ && P < (G_R + 2) * G_XP) ? off : VCG_OOB;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, dst, 16, off, 0, 0, 0);
-            }
+        for (int par = 0; par < 2; ++par) {
+            pdy[par] = (2 * par + lw) * 8 + l3;
+            rdy[par] = (unsigned)(pdy[par] * 128 + ((l7 ^ (4 * ((pdy[par] >> 1) & 1))) * 16));         // stored chunk l7 holds source chunk l7 ^ 4*((pixel >> 1) & 1)
         }
-    };
+        int xr[NX], xc[NX];
+        unsigned rxo[NX];
+        static_for<NX>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            const int P = j * 16 + lw * 8 + l3, row = P / G_XP, col = P - row * G_XP;
+            xr[j] = P < (G_R + 2) * G_XP ? row : 0x40000000;                                           // (slots past the halo: never in range)
+            xc[j] = col;
+            rxo[j] = (unsigned)((row * p.w_ + col) * 128 + ((l7 ^ (4 * ((P >> 1) & 1))) * 16));
+        });
+        auto issue = [&](int tile, int buf) {
+            const int txi = tile % p.tiles_x, t2 = tile / p.tiles_x, tyi = t2 % p.tiles_y, img = t2 / p.tiles_y;
+            const int y0 = tyi * G_R, x0 = txi * G_C;
+            const vcg_rsrc qdy = make_rsrc(p.dy + img * img_bytes, (unsigned long)img_bytes), qx = make_rsrc(p.x + img * img_bytes, (unsigned long)img_bytes);
+            const unsigned dybase = (unsigned)((y0 * p.w_ + x0) * 128), xbase = (unsigned)(((y0 - 1) * p.w_ + x0 - 1) * 128);   // (xbase: modulo 2^32)
+            const int wlim = p.w_ - x0;
+            unsigned char* stage = smem + buf * G_BUF + lw * 1024;
+            static_for<KDY>([&](auto kc) {
+                constexpr int k = decltype(kc)::value, row = k >> 1, par = k & 1;
+                const int lim = y0 + row < p.h ? wlim : 0;                                            // scalar: a row below the image admits no column
+                const unsigned off = pdy[par] < lim ? dybase + (unsigned)(row * p.w_ * 128) + rdy[par] : VCG_OOB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(qdy, (void __attribute__((address_space(3)))*)(stage + k * (G_NL * 1024)), 16, off, 0, 0, 0);
+            });
+            static_for<NX>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                const bool ok = (unsigned)(xr[j] + y0 - 1) < (unsigned)p.h && (unsigned)(xc[j] + x0 - 1) < (unsigned)p.w_;
+                const unsigned off = ok ? xbase + rxo[j] : VCG_OOB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(qx, (void __attribute__((address_space(3)))*)(stage + (KDY + j) * (G_NL * 1024)), 16, off, 0, 0, 0);
+            });
+        };
+        // stage t + 1 is requested right behind barrier t (which frees it) and has landed before barrier t + 1
+        int tile = blockIdx.x, buf = 0;
+        if (tile < p.total) issue(tile, 0);
+        for (; tile < p.total; tile += gridDim.x, buf ^= 1) {
+            WG_STAMP(wt0);
+            __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): this wave's half of the stage has landed
+            WG_STAMP(wt1);
+            lds_barrier();
+            WG_STAMP(wt2);
+            const int next = tile + gridDim.x;
+            if (next < p.total) issue(next, buf ^ 1);
+            WG_STAMP(wt3);
+#ifdef VCG_WG_STAMPS
+            ws0 += wt1 - wt0, ws1 += wt2 - wt1, ws2 += wt3 - wt2, ++wcnt;
+#endif
+        }
+#ifdef VCG_WG_STAMPS
+        if (lane == 0 && blockIdx.x < 256) {
+            unsigned long long* o = vcg_wg_stamp_sums + (blockIdx.x * G_NWT + wv) * 6;
+            o[0] = ws0, o[1] = ws1, o[2] = ws2, o[3] = 0, o[4] = wcnt, o[5] = __builtin_amdgcn_s_memtime() - wk0;
+        }
+#endif
+        lds_barrier();                               // the two barriers of the compute waves' exchange below
+        lds_barrier();
+        return;
+    }
 
     int tile = blockIdx.x, buf = 0;
-    if (tile < p.total) dma(tile, 0);
     for (; tile < p.total; tile += gridDim.x, buf ^= 1) {
-        __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0): this wave's part of the stage has landed
-        lds_barrier();                               // ... and everyone else's; the other buffer is free again
-        const int next = tile + gridDim.x;
-        if (next < p.total) dma(next, buf ^ 1);
+        WG_STAMP(wt0);
+        WG_STAMP(wt1);
+        lds_barrier();                               // the loaders' stage has landed; the other buffer is free again
+        WG_STAMP(wt2);
+        WG_STAMP(wt3);
         const unsigned lb = lds0 + buf * G_BUF;
 
         // 8 k-steps of 16 pixels: rows ph*4 .. ph*4+3, column halves 0/1
@@ -190,7 +251,17 @@ __global__ __launch_bounds__(G_NW * 64, 1) void wgrad3x3_c64_bf16_kernel(WgParam
                     }
                 }
         });
+        WG_STAMP(wt4);
+#ifdef VCG_WG_STAMPS
+        ws0 += wt1 - wt0, ws1 += wt2 - wt1, ws2 += wt3 - wt2, ws3 += wt4 - wt3, ++wcnt;
+#endif
     }
+#ifdef VCG_WG_STAMPS
+    if (lane == 0 && blockIdx.x < 256) {
+        unsigned long long* o = vcg_wg_stamp_sums + (blockIdx.x * G_NWT + wv) * 6;
+        o[0] = ws0, o[1] = ws1, o[2] = ws2, o[3] = ws3, o[4] = wcnt, o[5] = __builtin_amdgcn_s_memtime() - wk0;
+    }
+#endif
 
     // the two pixel-half waves of a tap row add their blocks through LDS (the stage buffers are free now): one raw
     // register dump per tap row and workgroup (coalesced), decoded by the reduction
@@ -303,12 +374,19 @@ int vcg_conv2d_bf16_wgrad(const vcg_conv_desc* d, const void* x, const void* dy,
         attr_set = true;
     }
     const int grid = p.total < G_GRID ? p.total : G_GRID;
-    wgrad3x3_c64_bf16_kernel<<<grid, G_NW * 64, 2 * G_BUF, stream>>>(p);
+    wgrad3x3_c64_bf16_kernel<<<grid, G_NWT * 64, 2 * G_BUF, stream>>>(p);
     VCG_LAUNCH_CHECK();
     static_assert(G_WAVE_FLOATS % 64 == 0, "wgrad3x3 reduce: 64 raw columns per block stay inside one tap row");
     wgrad3x3_c64_reduce2_kernel<<<3 * G_WAVE_FLOATS / 64 + 1, 1024, 0, stream>>>((const float*)ws, p.wsb, grid, dw_hwio, dbias);
     VCG_LAUNCH_CHECK();
     return VCG_OK;
 }
+
+#ifdef VCG_WG_STAMPS
+int vcg_debug_wg_stamps(unsigned long long* host_out) {
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(vcg_wg_stamp_sums), sizeof(unsigned long long) * 256 * G_NWT * 6);
+}
+#endif
 
 }  // extern "C"
