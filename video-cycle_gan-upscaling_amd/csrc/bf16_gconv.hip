@@ -215,14 +215,18 @@ __device__ __forceinline__ void gl_barrier() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
-template <int SP>
+// HALF: a layer with 64 output channels (the data gradient of a 64-channel layer, the transposed convolution's data gradient) would leave two
+// of the four waves without a 32-channel block; there a wave owns one of the TWO blocks x one HALF of the tile's rows instead (no statistics in this form).
+template <int SP, bool HALF>
 __global__ __launch_bounds__(256, 1) void gconv_lds_bf16_kernel(const GlParams p) {
+    constexpr int TRW = HALF ? GL_TR / 2 : GL_TR;                // output rows per wave
     constexpr int HR = GL_TR + SP, HC = GL_TC + SP, ROWB = HC * 128, XB = HR * ROWB, CH16 = XB / 16;
     constexpr int NDMA = (CH16 + 255) / 256, BUF = NDMA * 4096, G = (SP + 1) * 4;
     static_assert(2 * BUF <= 160 * 1024, "gconv_lds: LDS");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, hh = lane >> 5;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int mw = HALF ? (wv & 1) : wv, r0 = HALF ? (wv >> 1) * TRW : 0;      // 32-channel block inside the group, first row inside the tile
     const int nchunk = (p.kch >> 6) * p.nplanes, ksteps = p.kch >> 4;      // chunk = (parity plane, 64 input channels), plane-major
     const long img_in = (long)p.ih * p.iw * p.kch * 2, img_out = (long)p.oh * p.ow * p.mch * 2;
     const vcg_rsrc rw = make_rsrc(p.wf, p.wbytes);
@@ -265,9 +269,9 @@ __global__ __launch_bounds__(256, 1) void gconv_lds_bf16_kernel(const GlParams p
     __builtin_amdgcn_s_waitcnt(0x0F70);
     gl_barrier();
 
-    f32x16 acc[GL_TR];
+    f32x16 acc[TRW];
 #pragma unroll
-    for (int n = 0; n < GL_TR; ++n)
+    for (int n = 0; n < TRW; ++n)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[n][e] = 0.f;
     // statistics for the normalisation behind the convolution (p.stats): per lane [sum | sum of squares][q][j] of its 16 channels
@@ -284,14 +288,14 @@ __global__ __launch_bounds__(256, 1) void gconv_lds_bf16_kernel(const GlParams p
         const GlSrc nxt = last_chunk ? decode(has_next ? npair : pair) : cur;
         const int nc = last_chunk ? 0 : c + 1;
         const unsigned char* xb = smem + buf * BUF;
-        const int mtile = cur.mg * 4 + wv;
+        const int mtile = cur.mg * (HALF ? 2 : 4) + mw;
         const int pli = c / cpp, cc = c - pli * cpp;
 
-        bf16x8 fb[2][HR], a[2][SP + 1];
+        bf16x8 fb[2][TRW + SP], a[2][SP + 1];
         auto frag = [&](int g, int b) {
             const int d = g >> 2, s = g & 3;
 #pragma unroll
-            for (int j = 0; j < HR; ++j) fb[b][j] = *(const bf16x8*)(xb + j * ROWB + (boff[d] ^ (s << 5)));
+            for (int j = 0; j < TRW + SP; ++j) fb[b][j] = *(const bf16x8*)(xb + (r0 + j) * ROWB + (boff[d] ^ (s << 5)));
         };
         auto wfrag = [&](int g, int b) {
             const int d = g >> 2, s = g & 3;
@@ -313,7 +317,7 @@ __global__ __launch_bounds__(256, 1) void gconv_lds_bf16_kernel(const GlParams p
             for (int dy = 0; dy <= SP; ++dy) {
                 if (p.pl[pli].wt[dy * (SP + 1) + (g >> 2)] < 0) continue;     // uniform: a phase / parity plane lacks some offsets of the box
 #pragma unroll
-                for (int n = 0; n < GL_TR; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cb][dy], fb[cb][n + dy], acc[n], 0, 0, 0);
+                for (int n = 0; n < TRW; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cb][dy], fb[cb][n + dy], acc[n], 0, 0, 0);
             }
         }
         if (last_chunk) {
@@ -329,8 +333,8 @@ __global__ __launch_bounds__(256, 1) void gconv_lds_bf16_kernel(const GlParams p
 #pragma unroll
                 for (int j = 0; j < 8; ++j) bs[j] = p.bias && mtile < p.mblocks ? p.bias[co + j] : 0.f;
 #pragma unroll
-                for (int n = 0; n < GL_TR; ++n) {
-                    const int ly = cur.ty * GL_TR + n, oy = ly * p.osy + p.ooy;
+                for (int n = 0; n < TRW; ++n) {
+                    const int ly = cur.ty * GL_TR + r0 + n, oy = ly * p.osy + p.ooy;
                     const bool ok = ly < p.loh && lx < p.low && oy < p.oh && ox < p.ow && mtile < p.mblocks;
                     unsigned off = ((unsigned)(oy * p.ow + ox) * (unsigned)p.mch + (unsigned)co) * 2u;
                     asm volatile("" : "+v"(off));
@@ -355,7 +359,7 @@ __global__ __launch_bounds__(256, 1) void gconv_lds_bf16_kernel(const GlParams p
                     }
                     const u32x4 ob = __builtin_bit_cast(u32x4, o);
                     __builtin_amdgcn_raw_buffer_store_b128(ob, ry, (int)off, 0, 0);
-                    if (p.stats) {                                   // (uniform) the values as stored, zero outside the tensor
+                    if (!HALF && p.stats) {                          // (uniform) the values as stored, zero outside the tensor
                         const unsigned m = ok ? 0xFFFFFFFFu : 0u;
 #pragma unroll
                         for (int d = 0; d < 4; ++d) {
@@ -369,7 +373,7 @@ __global__ __launch_bounds__(256, 1) void gconv_lds_bf16_kernel(const GlParams p
                     }
                 }
             }
-            if (p.stats) {
+            if (!HALF && p.stats) {
                 // one record per tile: lane (r, hh) ends up with value r = [stat][q][j] summed over the tile's 8 x 32 pixels
                 const float t = half_wave_reduce_scatter32(sacc, r);
                 const long tile = ((long)cur.img * p.tiles_y + cur.ty) * p.tiles_x + cur.tx;
@@ -378,7 +382,7 @@ __global__ __launch_bounds__(256, 1) void gconv_lds_bf16_kernel(const GlParams p
                 for (int i = 0; i < 32; ++i) sacc[i] = 0.f;
             }
 #pragma unroll
-            for (int n = 0; n < GL_TR; ++n)
+            for (int n = 0; n < TRW; ++n)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[n][e] = 0.f;
         }
@@ -420,23 +424,23 @@ __global__ void f32_to_bf16_kernel(const float* __restrict__ x, __bf16* __restri
     if (i < count) y[i] = (__bf16)x[i];
 }
 
-template <int SP>
+template <int SP, bool HALF>
 int launch_gconv_lds_sp(const GlParams& q, int grid, hipStream_t st) {
     constexpr int HR = GL_TR + SP, HC = GL_TC + SP, CH16 = HR * HC * 8, NDMA = (CH16 + 255) / 256, LDS = 2 * NDMA * 4096;
     static bool attr = false;
     if (!attr) {
-        hipError_t e = hipFuncSetAttribute((const void*)gconv_lds_bf16_kernel<SP>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        hipError_t e = hipFuncSetAttribute((const void*)gconv_lds_bf16_kernel<SP, HALF>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) return (int)e;
         attr = true;
     }
-    hipLaunchKernelGGL(gconv_lds_bf16_kernel<SP>, dim3(grid), dim3(256), LDS, st, q);
+    hipLaunchKernelGGL((gconv_lds_bf16_kernel<SP, HALF>), dim3(grid), dim3(256), LDS, st, q);
     VCG_LAUNCH_CHECK();
     return VCG_OK;
 }
 
 // the LDS-tiled kernel where it applies (input stride 1 or 2, 64-channel input chunks, >= 64 output channels, the taps of a parity plane
 // inside a 5x5 box, images below 4 GiB, enough tiles to fill the chip); VCG_GCONV_LDS=0 forces the streaming kernel (A/B aid)
-bool plan_gconv_lds(const GcParams& p, GlParams& q, int& spe_out) {
+bool plan_gconv_lds(const GcParams& p, GlParams& q, int& spe_out, bool& half_out) {
     static const bool off = getenv("VCG_GCONV_LDS") && atoi(getenv("VCG_GCONV_LDS")) == 0;
     if (off || p.isy != p.isx || p.isy < 1 || p.isy > 2 || p.kch % 64 || p.mblocks < 2 || p.ntaps < 1) return false;
     if ((long)p.ih * p.iw * p.kch * 2 > 0xFFFFFFE0l || (long)p.oh * p.ow * p.mch * 2 > 0xFFFFFFE0l) return false;
@@ -476,7 +480,9 @@ bool plan_gconv_lds(const GcParams& p, GlParams& q, int& spe_out) {
     q.n = p.n; q.ih = p.ih; q.iw = p.iw; q.kch = p.kch; q.oh = p.oh; q.ow = p.ow; q.mch = p.mch; q.loh = p.loh; q.low = p.low;
     q.osy = p.osy; q.osx = p.osx; q.ooy = p.ooy; q.oox = p.oox; q.mblocks = p.mblocks; q.act = p.act; q.alpha = p.alpha; q.mask_slope = p.mask_slope;
     q.isy = p.isy; q.isx = p.isx; q.stats = p.stats;
-    q.tiles_x = ceil_div(p.low, GL_TC); q.tiles_y = ceil_div(p.loh, GL_TR); q.mgroups = (p.mblocks + 3) / 4;
+    q.tiles_x = ceil_div(p.low, GL_TC); q.tiles_y = ceil_div(p.loh, GL_TR);
+    half_out = p.mblocks == 2 && p.stats == nullptr;            // 64 output channels: waves = 2 channel blocks x 2 row halves
+    q.mgroups = half_out ? 1 : (p.mblocks + 3) / 4;
     const long pairs = (long)p.n * q.tiles_x * q.tiles_y * q.mgroups;
     if (pairs < 64 || pairs > 0x7fffffffL) return false;        // too little work for 256 one-workgroup CUs: the streaming kernel's small tiles fill the chip better
     q.pairs = (int)pairs;
@@ -487,13 +493,14 @@ bool plan_gconv_lds(const GcParams& p, GlParams& q, int& spe_out) {
 bool try_gconv_lds(const GcParams& p, hipStream_t st, int* rc) {
     GlParams q;
     int spe = 1;
-    if (!plan_gconv_lds(p, q, spe)) return false;
+    bool half = false;
+    if (!plan_gconv_lds(p, q, spe, half)) return false;
     const int grid = q.pairs < 256 ? q.pairs : 256;
     switch (spe) {
-        case 1: *rc = launch_gconv_lds_sp<1>(q, grid, st); break;
-        case 2: *rc = launch_gconv_lds_sp<2>(q, grid, st); break;
-        case 3: *rc = launch_gconv_lds_sp<3>(q, grid, st); break;
-        default: *rc = launch_gconv_lds_sp<4>(q, grid, st); break;
+        case 1: *rc = half ? launch_gconv_lds_sp<1, true>(q, grid, st) : launch_gconv_lds_sp<1, false>(q, grid, st); break;
+        case 2: *rc = half ? launch_gconv_lds_sp<2, true>(q, grid, st) : launch_gconv_lds_sp<2, false>(q, grid, st); break;
+        case 3: *rc = half ? launch_gconv_lds_sp<3, true>(q, grid, st) : launch_gconv_lds_sp<3, false>(q, grid, st); break;
+        default: *rc = half ? launch_gconv_lds_sp<4, true>(q, grid, st) : launch_gconv_lds_sp<4, false>(q, grid, st); break;
     }
     return true;
 }
@@ -583,7 +590,8 @@ int vcg_conv2d_nhwc_bf16_stats_records(const vcg_conv_desc* d, int stats_mode) {
     fwd_params(d, p);
     GlParams q;
     int spe = 1;
-    if (!plan_gconv_lds(p, q, spe)) return VCG_E_UNSUPPORTED;
+    bool half = false;                                          // (the tile grid -- the record count -- is the same in both forms)
+    if (!plan_gconv_lds(p, q, spe, half)) return VCG_E_UNSUPPORTED;
     const long per_img = (long)q.tiles_x * q.tiles_y, all = per_img * d->n;
     if (all > 0x3fffffffL) return VCG_E_UNSUPPORTED;
     return (int)(stats_mode == VCG_STATS_INSTANCE ? per_img : all);
