@@ -1,7 +1,7 @@
-# round 3: LDS-tiled generic convolution with a ring of three stages: the transposed convolution's backward, parity, rates, C3 / C4 / kernel stats
+# round 3: LDS-tiled generic convolution, 64-output-channel form with loader waves + a ring of three stages: the transposed convolution's backward, parity, rates, C3 / C4 / kernel stats
 set -o pipefail
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
-python scripts/micro/convt_bwd_bench.py > gpurun_out/ring_ctd.txt 2>&1 && VCG_GCONV_PLANE_INNER=1 python scripts/micro/convt_bwd_bench.py >> gpurun_out/ring_ctd.txt 2>&1 && cat gpurun_out/ring_ctd.txt &&
+timeout -k 10 120 python scripts/micro/convt_bwd_bench.py > gpurun_out/ring_ctd.txt 2>&1 && cat gpurun_out/ring_ctd.txt &&
 timeout -k 10 800 python -m pytest tests/test_bf16_gpu.py tests/test_fullsize_bf16_gpu.py -m gpu -x -q -k "generic_conv or discriminator or train_step or trunk_generator or upsampling or fullsize_generic or critics or transpose or stats_epilogue" > gpurun_out/ring_tests.log 2>&1; rc=$?; tail -3 gpurun_out/ring_tests.log; [ $rc -eq 0 ] || exit $rc
 timeout -k 10 300 python scripts/kbench_gconv.py > gpurun_out/ring_kbench_c3.txt 2>&1 && cat gpurun_out/ring_kbench_c3.txt &&
 timeout -k 10 300 python scripts/kbench_gconv.py c4 > gpurun_out/ring_kbench_c4.txt 2>&1 && cat gpurun_out/ring_kbench_c4.txt &&

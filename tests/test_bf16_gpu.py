@@ -633,6 +633,9 @@ GCONV_CASES = [
     (64, 128, 4, 2, 1, 4, 128, 96),            # stride-2 forward through the four parity planes (PatchGAN block 2), 64-channel gradient groups
     (128, 128, 3, 1, "same", 5, 67, 45),       # odd sizes on the LDS kernel, two input chunks
     (128, 128, 3, 2, "same", 7, 75, 83),       # stride 2 on odd sizes: TF-SAME pads (1,1), parity planes of unequal extent
+    (64, 128, 4, 1, 1, 8, 40, 50),             # 4x4 box with a 64-channel data gradient: the row-split form with loader waves, three stages of 52 KiB
+    (128, 64, 4, 1, 1, 8, 40, 50),             # ... and a 64-channel forward in that form
+    (64, 64, 3, 2, "same", 8, 66, 70),         # 64 -> 64 stride 2: that form on parity planes (forward) and phases (data gradient), ragged
 ]
 
 

@@ -217,12 +217,21 @@ __device__ __forceinline__ void gl_barrier() {
 
 // HALF: a layer with 64 output channels (the data gradient of a 64-channel layer, the transposed convolution's data gradient) would leave two
 // of the four waves without a 32-channel block; there a wave owns one of the TWO blocks x one HALF of the tile's rows instead (no statistics in this form).
+// The HALF form (its waves hold half the accumulators: two fit a SIMD) also runs four LOADER waves that do nothing but request the halos:
+// a wave's vector-memory loads return in order, so in the one-role form the weight fragments of a k-group queue behind the halo pieces
+// requested before them, and a halo request that waits for room in the memory pipe holds up the MFMAs behind it.  The loaders' queue holds
+// halo pieces only, which also lets them run a ring of THREE stages (two entries in flight; the same ring in the one-role form was
+// measured slower, profiles/r03_gconv_ring_ab.txt).  What it serves: the transposed convolution's data gradient -- 36 MFMAs per wave and
+// entry over a 1.07 GB tensor -- and the 64-channel data gradients of the critics.
 template <int SP, bool HALF>
-__global__ __launch_bounds__(256, 1) void gconv_lds_bf16_kernel(const GlParams p) {
+__global__ __launch_bounds__(HALF ? 512 : 256, 1) void gconv_lds_bf16_kernel(const GlParams p) {
     constexpr int TRW = HALF ? GL_TR / 2 : GL_TR;                // output rows per wave
     constexpr int HR = GL_TR + SP, HC = GL_TC + SP, ROWB = HC * 128, XB = HR * ROWB, CH16 = XB / 16;
     constexpr int NDMA = (CH16 + 255) / 256, BUF = NDMA * 4096, G = (SP + 1) * 4;
-    static_assert(2 * BUF <= 160 * 1024, "gconv_lds: LDS");
+    constexpr bool LOADERS = HALF;
+    constexpr int NS = LOADERS && 3 * BUF <= 160 * 1024 ? 3 : 2, AHEAD = NS - 1;
+    constexpr int WAIT_ONE_BEHIND = (NDMA & 15) | ((NDMA >> 4) << 14) | 0x0F70;     // s_waitcnt vmcnt(NDMA)
+    static_assert(2 * BUF <= 160 * 1024 && NDMA < 64, "gconv_lds: LDS / vmcnt");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, hh = lane >> 5;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -245,8 +254,9 @@ __global__ __launch_bounds__(256, 1) void gconv_lds_bf16_kernel(const GlParams p
         return GlSrc{img, ty * GL_TR, tx * GL_TC, mg, ty, tx};
     };
     const int cpp = p.kch >> 6;                                  // chunks per plane
+    const int dtid = LOADERS ? tid - 256 : tid, dwv = LOADERS ? wv - 4 : wv;     // the staging thread / wave index (loader waves: 4..7)
     auto dma = [&](const GlSrc& sc, int c, int buf, int k, bool live) {
-        const int sl = k * 256 + tid, P = sl >> 3, row = P / HC, col = P - row * HC;
+        const int sl = k * 256 + dtid, P = sl >> 3, row = P / HC, col = P - row * HC;
         const int cs = (sl & 7) ^ ((col >> 1) & 7);                                // stored chunk (sl & 7) holds source chunk cs
         const int pli = c / cpp, cc = c - pli * cpp;
         const int iy = p.isy * (sc.y0 + p.pl[pli].dy0 + row) + p.pl[pli].py, ix = p.isx * (sc.x0 + p.pl[pli].dx0 + col) + p.pl[pli].px;
@@ -255,18 +265,56 @@ __global__ __launch_bounds__(256, 1) void gconv_lds_bf16_kernel(const GlParams p
         asm volatile("" : "+v"(off));                            // a select, not a branch around the arithmetic
         off = ok ? off : VCG_OOB;
         const vcg_rsrc rx = make_rsrc((const unsigned char*)p.x + sc.img * img_in, (unsigned long)img_in);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (void __attribute__((address_space(3)))*)(smem + buf * BUF + (k * 256 + wv * 64) * 16), 16, off, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (void __attribute__((address_space(3)))*)(smem + buf * BUF + (k * 256 + dwv * 64) * 16), 16, off, 0, 0, 0);
     };
     auto afrag = [&](int wt, int ks, int mtile) {      // (a wave past the last 32-channel block of a ragged group computes zeros)
         return ld_frag(rw, wt < 0 || mtile >= p.mblocks ? VCG_OOB : (unsigned)(((wt * ksteps + ks) * p.mblocks + mtile) * 1024 + lane * 16));
     };
 
+    // the entries (pair, chunk) in the order this workgroup walks them
+    auto succ = [&](int& pr, int& ch) {
+        if (ch + 1 == nchunk) { pr += gridDim.x; ch = 0; } else ++ch;
+    };
     int pair = blockIdx.x;
     if (pair >= p.pairs) return;
     GlSrc cur = decode(pair);
+    if (LOADERS && wv >= 4) {
+        // loader waves: entry i + AHEAD is requested right behind barrier i (which frees its stage) and entry i + 1 has landed before
+        // barrier i + 1.  Every request issues NDMA pieces per wave (past the last entry: zero-record descriptors), so "at most NDMA
+        // outstanding" always means "all but the youngest entry's pieces".
+        auto request = [&](int pr, int ch, int buf) {
+            const bool live = pr < p.pairs;
+            const GlSrc sc = decode(live ? pr : (int)blockIdx.x);
 #pragma unroll
-    for (int k = 0; k < NDMA; ++k) dma(cur, 0, 0, k, true);
-    __builtin_amdgcn_s_waitcnt(0x0F70);
+            for (int k = 0; k < NDMA; ++k) dma(sc, ch, buf, k, live);
+        };
+        int pr = pair, ch = 0, ap = pair, ac = 0, abuf = 0;      // the entry being multiplied; the next one to request and its stage
+        for (int a = 0; a < AHEAD; ++a) {
+            request(ap, ac, abuf);
+            succ(ap, ac);
+            abuf = abuf + 1 == NS ? 0 : abuf + 1;
+        }
+        if (AHEAD == 2) __builtin_amdgcn_s_waitcnt(WAIT_ONE_BEHIND);
+        else __builtin_amdgcn_s_waitcnt(0x0F70);
+        gl_barrier();
+        while (true) {
+            request(ap, ac, abuf);
+            succ(ap, ac);
+            abuf = abuf + 1 == NS ? 0 : abuf + 1;
+            succ(pr, ch);
+            if (pr >= p.pairs) break;                            // the compute waves multiply their last entry without another barrier
+            if (AHEAD == 2) __builtin_amdgcn_s_waitcnt(WAIT_ONE_BEHIND);
+            else __builtin_amdgcn_s_waitcnt(0x0F70);
+            gl_barrier();
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70);                      // (nothing of this wave may still be writing LDS when the workgroup ends)
+        return;
+    }
+    if (!LOADERS) {
+#pragma unroll
+        for (int k = 0; k < NDMA; ++k) dma(cur, 0, 0, k, true);
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+    }
     gl_barrier();
 
     f32x16 acc[TRW];
@@ -311,8 +359,10 @@ __global__ __launch_bounds__(256, 1) void gconv_lds_bf16_kernel(const GlParams p
                 wfrag(g + 1, cb ^ 1);                                  // weights one group ahead (older than this group's DMA pieces)
                 frag(g + 1, cb ^ 1);
             }
+            if (!LOADERS) {
 #pragma unroll
-            for (int k = g; k < NDMA; k += G) dma(nxt, nc, buf ^ 1, k, has_next);
+                for (int k = g; k < NDMA; k += G) dma(nxt, nc, buf ^ 1, k, has_next);
+            }
 #pragma unroll
             for (int dy = 0; dy <= SP; ++dy) {
                 if (p.pl[pli].wt[dy * (SP + 1) + (g >> 2)] < 0) continue;     // uniform: a phase / parity plane lacks some offsets of the box
@@ -388,9 +438,9 @@ __global__ __launch_bounds__(256, 1) void gconv_lds_bf16_kernel(const GlParams p
         }
         if (last_chunk && !has_next) break;
         // the next (tile, chunk)'s pieces were issued under this chunk's MFMAs: retire them, then the one barrier of the chunk
-        __builtin_amdgcn_s_waitcnt(0x0F70);
+        if (!LOADERS) __builtin_amdgcn_s_waitcnt(0x0F70);
         gl_barrier();
-        buf ^= 1;
+        buf = buf + 1 == NS ? 0 : buf + 1;
         c = nc;
         if (last_chunk) { pair = npair; cur = nxt; }
     }
@@ -426,14 +476,14 @@ __global__ void f32_to_bf16_kernel(const float* __restrict__ x, __bf16* __restri
 
 template <int SP, bool HALF>
 int launch_gconv_lds_sp(const GlParams& q, int grid, hipStream_t st) {
-    constexpr int HR = GL_TR + SP, HC = GL_TC + SP, CH16 = HR * HC * 8, NDMA = (CH16 + 255) / 256, LDS = 2 * NDMA * 4096;
+    constexpr int HR = GL_TR + SP, HC = GL_TC + SP, CH16 = HR * HC * 8, NDMA = (CH16 + 255) / 256, LDS = (HALF && 3 * NDMA * 4096 <= 160 * 1024 ? 3 : 2) * NDMA * 4096;
     static bool attr = false;
     if (!attr) {
         hipError_t e = hipFuncSetAttribute((const void*)gconv_lds_bf16_kernel<SP, HALF>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) return (int)e;
         attr = true;
     }
-    hipLaunchKernelGGL((gconv_lds_bf16_kernel<SP, HALF>), dim3(grid), dim3(256), LDS, st, q);
+    hipLaunchKernelGGL((gconv_lds_bf16_kernel<SP, HALF>), dim3(grid), dim3(HALF ? 512 : 256), LDS, st, q);
     VCG_LAUNCH_CHECK();
     return VCG_OK;
 }
@@ -481,7 +531,7 @@ bool plan_gconv_lds(const GcParams& p, GlParams& q, int& spe_out, bool& half_out
     q.osy = p.osy; q.osx = p.osx; q.ooy = p.ooy; q.oox = p.oox; q.mblocks = p.mblocks; q.act = p.act; q.alpha = p.alpha; q.mask_slope = p.mask_slope;
     q.isy = p.isy; q.isx = p.isx; q.stats = p.stats;
     q.tiles_x = ceil_div(p.low, GL_TC); q.tiles_y = ceil_div(p.loh, GL_TR);
-    half_out = p.mblocks == 2 && p.stats == nullptr;            // 64 output channels: waves = 2 channel blocks x 2 row halves
+    half_out = p.mblocks == 2 && p.stats == nullptr && spe <= 3;     // 64 output channels: waves = 2 channel blocks x 2 row halves (+ loaders, three stages)
     q.mgroups = half_out ? 1 : (p.mblocks + 3) / 4;
     const long pairs = (long)p.n * q.tiles_x * q.tiles_y * q.mgroups;
     if (pairs < 64 || pairs > 0x7fffffffL) return false;        // too little work for 256 one-workgroup CUs: the streaming kernel's small tiles fill the chip better
