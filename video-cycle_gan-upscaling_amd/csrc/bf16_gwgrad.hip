@@ -138,20 +138,21 @@ __global__ __launch_bounds__((GwCfg<K, S>::NTH), 1) void gwgrad_bf16_kernel(GwPa
         const int gy0 = oy0 * S - p.pt, gx0 = ox0 * S - p.pl;
         const vcg_rsrc rdy = make_rsrc(p.dy + img * dyimg, (unsigned long)dyimg), rx = make_rsrc(p.x + img * ximg, (unsigned long)ximg);
         // byte offsets of the tile's first pixels (the x one may be "negative": it is only used modulo 2^32 under a passed range check)
-        const unsigned dybase = (unsigned)((oy0 * p.ow + ox0) * dypix + cob * 128), xbase = (unsigned)((gy0 * p.w_ + gx0) * xpix + cib * 128);
+        const unsigned dybase = (unsigned)(oy0 * p.ow + ox0) * (unsigned)dypix + (unsigned)(cob * 128);
+        const unsigned xbase = (unsigned)(gy0 * p.w_ + gx0) * (unsigned)xpix + (unsigned)(cib * 128);
 #pragma unroll
         for (int k = 0; k < C::NDMA; ++k) {
             const int sb = k * C::NTH + wv * 64;                              // first slot of this wave's piece (scalar)
             void __attribute__((address_space(3)))* dst = (void __attribute__((address_space(3)))*)(smem + buf * C::BUF + sb * 16);
             if (sb < C::DYB / 16) {
                 const int m = sb >> 6, row = m / (C::TC / 8), pos = (m % (C::TC / 8)) * 8 + l3;      // TC = 16: a piece is half a tile row
-                const unsigned rel = (unsigned)((row * p.ow + pos) * dypix + ((l7 ^ (4 * ((pos >> 1) & 1))) * 16));
+                const unsigned rel = (unsigned)(row * p.ow + pos) * (unsigned)dypix + (unsigned)((l7 ^ (4 * ((pos >> 1) & 1))) * 16);
                 const bool ok = oy0 + row < p.oh && ox0 + pos < p.ow;
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rdy, dst, 16, ok ? dybase + rel : VCG_OOB, 0, 0, 0);
             } else {
                 const int L = ((sb - C::DYB / 16) >> 3) + l3, row = L / C::PITCH, pos = L - row * C::PITCH;
                 const int col = S == 2 ? (pos < C::HALF ? 2 * pos : 2 * (pos - C::HALF) + 1) : pos;
-                const unsigned rel = (unsigned)((row * p.w_ + col) * xpix + ((l7 ^ (4 * ((pos >> 1) & 1))) * 16));
+                const unsigned rel = (unsigned)(row * p.w_ + col) * (unsigned)xpix + (unsigned)((l7 ^ (4 * ((pos >> 1) & 1))) * 16);
                 const bool ok = row < C::XR && col < C::XC && pos < C::XPOS && (unsigned)(gy0 + row) < (unsigned)p.h && (unsigned)(gx0 + col) < (unsigned)p.w_;
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, dst, 16, ok ? xbase + rel : VCG_OOB, 0, 0, 0);
             }

@@ -149,19 +149,19 @@ __global__ __launch_bounds__(G_NWT * 64, 1) void wgrad3x3_c64_bf16_kernel(WgPara
             const int P = j * 16 + lw * 8 + l3, row = P / G_XP, col = P - row * G_XP;
             xr[j] = P < (G_R + 2) * G_XP ? row : 0x40000000;                                           // (slots past the halo: never in range)
             xc[j] = col;
-            rxo[j] = (unsigned)((row * p.w_ + col) * 128 + ((l7 ^ (4 * ((P >> 1) & 1))) * 16));
+            rxo[j] = (unsigned)(row * p.w_ + col) * 128u + (unsigned)((l7 ^ (4 * ((P >> 1) & 1))) * 16);
         });
         auto issue = [&](int tile, int buf) {
             const int txi = tile % p.tiles_x, t2 = tile / p.tiles_x, tyi = t2 % p.tiles_y, img = t2 / p.tiles_y;
             const int y0 = tyi * G_R, x0 = txi * G_C;
             const vcg_rsrc qdy = make_rsrc(p.dy + img * img_bytes, (unsigned long)img_bytes), qx = make_rsrc(p.x + img * img_bytes, (unsigned long)img_bytes);
-            const unsigned dybase = (unsigned)((y0 * p.w_ + x0) * 128), xbase = (unsigned)(((y0 - 1) * p.w_ + x0 - 1) * 128);   // (xbase: modulo 2^32)
+            const unsigned dybase = (unsigned)(y0 * p.w_ + x0) * 128u, xbase = (unsigned)((y0 - 1) * p.w_ + x0 - 1) * 128u;   // (xbase: modulo 2^32)
             const int wlim = p.w_ - x0;
             unsigned char* stage = smem + buf * G_BUF + lw * 1024;
             static_for<KDY>([&](auto kc) {
                 constexpr int k = decltype(kc)::value, row = k >> 1, par = k & 1;
                 const int lim = y0 + row < p.h ? wlim : 0;                                            // scalar: a row below the image admits no column
-                const unsigned off = pdy[par] < lim ? dybase + (unsigned)(row * p.w_ * 128) + rdy[par] : VCG_OOB;
+                const unsigned off = pdy[par] < lim ? dybase + (unsigned)(row * p.w_) * 128u + rdy[par] : VCG_OOB;
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(qdy, (void __attribute__((address_space(3)))*)(stage + k * (G_NL * 1024)), 16, off, 0, 0, 0);
             });
             static_for<NX>([&](auto jc) {
