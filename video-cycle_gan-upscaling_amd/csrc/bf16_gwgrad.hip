@@ -294,7 +294,8 @@ __global__ void gwgrad_bias_reduce_kernel(GwReduce p) {
     p.db[co] = s;
 }
 
-constexpr int GW_MAX_WG = 512;       // one 5- or 8-wave workgroup per CU: two rounds
+constexpr int GW_MAX_WG = 256;       // one 5- or 8-wave workgroup per CU (the ring of stages fills its LDS), ONE round: a second round would pay the
+                                     // pipeline ramp and the accumulator dump again and double the partial blocks the reduction reads
 
 struct GwPlan { int tiles_x, tiles_y, total, slabs, ci_blocks, co_blocks, nw, TR; size_t ws_part, ws_bytes; bool ok; };
 
