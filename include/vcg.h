@@ -345,6 +345,14 @@ int vcg_conv3ch_bf16_fwd(const vcg_conv_desc* d, const void* x, const void* wfra
  * cout = 64, pads 1; w_hwio: Keras' (kh,kw,3,64) kernel (fp32; its bf16 copy is the operand). */
 size_t vcg_conv3ch_bf16_dgrad_workspace_bytes(const vcg_conv_desc* d);
 int vcg_conv3ch_bf16_dgrad(const vcg_conv_desc* d, const void* dz, const float* w_hwio, float* dx, void* ws, size_t ws_bytes, vcg_stream_t stream);
+/* weight (+ bias) gradient of a layer that reads the 3-channel frames -- initial/conv (9x9, upscaling/upscaler/model.py:275), the critics'
+ * first layers (3x3 'same', model.py:839, 904; the PatchGAN's 4x4 stride 2) -- from the fp32 NCHW frames x [n][3][h][w] and the bf16 NHWC gradient
+ * dz [n][oh][ow][cout] in front of the layer's activation: both as bf16 MFMA operands (the roundings the forward kernel multiplies), fp32
+ * accumulation, dw in Keras' (kh,kw,3,cout) layout, dbias [cout] or NULL; deterministic.  cout % 64 == 0, even width; VCG_E_UNSUPPORTED
+ * otherwise (run vcg_conv2d_wgrad on an fp32 copy of dz).  Replaces the gradient of model.py:275 / :839 that Keras derives. */
+size_t vcg_conv3ch_bf16_wgrad_workspace_bytes(const vcg_conv_desc* d);
+int vcg_conv3ch_bf16_wgrad(const vcg_conv_desc* d, const float* x, const void* dz, float* dw_hwio, float* dbias, void* ws, size_t ws_bytes,
+                           vcg_stream_t stream);
 /* the training-mode form of vcg_conv9x9_from3_bf16_fwd: also stores z, the value in front of the PReLU (bf16 NHWC like y), which
  * vcg_prelu_bwd_nhwc_bf16 needs */
 int vcg_conv9x9_from3_bf16_fwd_train(const vcg_conv_desc* d, const void* x, const void* wfrag, const void* bias, const void* prelu_alpha,
@@ -356,6 +364,9 @@ int vcg_conv9x9_from3_bf16_fwd_train(const vcg_conv_desc* d, const void* x, cons
 int vcg_prelu_bwd_nhwc_bf16_records(int n, int hw);
 int vcg_prelu_bwd_nhwc_bf16(const void* d1, const void* d2, const void* z, const float* prelu_alpha, int n, int c, int hw, float* dz_nchw,
                             float* records, hipStream_t stream);
+/* the same with dz left as bf16 NHWC [n][hw][c] (what vcg_conv3ch_bf16_wgrad reads); same records */
+int vcg_prelu_bwd_nhwc_bf16_to_bf16(const void* d1, const void* d2, const void* z, const float* prelu_alpha, int n, int c, int hw, void* dz_nhwc,
+                                    float* records, hipStream_t stream);
 
 /* BatchNormalization / instance norm (+PReLU / LeakyReLU, +Add) on bf16 NHWC activations (model.py:20-25): statistics
  * and arithmetic in fp32.  vcg_norm_stats_bf16: per-channel (VCG_NORM_BATCH) or per-(n,c) (VCG_NORM_INSTANCE) mean and

@@ -734,8 +734,8 @@ def test_cout1_conv_bf16_fwd_dgrad_wgrad(rt, cin, k, padding, n, h, w):
 ])
 def test_first_conv_bf16_forward_and_gradients(rt, cout, k, stride, padding, slope, n, h, w):
     """FirstConvBf16 (vcg_conv3ch_bf16_fwd: fp32 NCHW frames -> bf16 NHWC, + bias + LeakyReLU) against the fp64 oracle on the same
-    bf16-rounded frames / kernel: output to 2^-8; weight / bias gradients (fp32 kernels on the fp32 frames, given the gradient in front of
-    the activation) to 1e-5 against autograd of the UNROUNDED convolution (the straight-through gradient of the roundings); the data
+    bf16-rounded frames / kernel: output to 2^-8; weight / bias gradients (vcg_conv3ch_bf16_wgrad: the bf16 copy of the frames x the bf16
+    gradient in front of the activation, fp32 accumulation) to 1e-5 against autograd with the straight-through gradient of the roundings; the data
     gradient (vcg_conv3ch_bf16_dgrad: bf16 kernel copy, virtual-channel convolution stored in bf16) to 2^-8."""
     from oracle import keras_ops as K
     from upscaler import _engine as E, _lib as L
@@ -756,7 +756,10 @@ def test_first_conv_bf16_forward_and_gradients(rt, cout, k, stride, padding, slo
     e_y = rel_err(_to_nchw_f32(rt, y), yr)
     # backward: dz given in bf16 NHWC
     dz = _bf16_round(torch.randn(*yr.shape, generator=g)).float()
-    xg = x.double().requires_grad_(True)
+    # the weight gradient multiplies dz by the bf16 copy of the frames (the forward's operand: vcg_conv3ch_bf16_wgrad); for odd widths the
+    # fp32 kernel on the fp32 frames serves
+    bf16_wgrad = rt.lib.vcg_conv3ch_bf16_wgrad_workspace_bytes(ctypes.byref(layer.desc(n, h, w))) > 0
+    xg = (_bf16_round(x) if bf16_wgrad else x).double().requires_grad_(True)
     wg = wk.double().requires_grad_(True)
     bg = bk.double().requires_grad_(True)
     (K.conv2d(xg, wg, bg, stride, padding) * dz.double()).sum().backward()

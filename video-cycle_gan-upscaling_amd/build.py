@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libvcg_hip.so")
-SOURCES = ["conv_fwd.hip", "conv_rowchain.hip", "conv_transpose.hip", "conv_wgrad.hip", "norm.hip", "elementwise.hip", "dense.hip", "bf16_conv.hip", "bf16_norm.hip", "bf16_wgrad.hip", "bf16_wgrad9.hip", "bf16_gconv.hip", "bf16_gwgrad.hip", "bf16_head.hip", "api.hip"]
+SOURCES = ["conv_fwd.hip", "conv_rowchain.hip", "conv_transpose.hip", "conv_wgrad.hip", "norm.hip", "elementwise.hip", "dense.hip", "bf16_conv.hip", "bf16_norm.hip", "bf16_wgrad.hip", "bf16_wgrad9.hip", "bf16_gconv.hip", "bf16_gwgrad.hip", "bf16_head.hip", "bf16_wgrad3.hip", "api.hip"]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-I", os.path.join(ROOT, "include"), "-I", CSRC,
          "-Wno-unused-value", "-Wno-c++20-extensions"]
 

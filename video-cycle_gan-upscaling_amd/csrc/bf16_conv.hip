@@ -1986,6 +1986,56 @@ int vcg_conv9x9_from3_bf16_fwd(const vcg_conv_desc* d, const void* x, const void
 
 static int prelu_bwd_gridx(int hw) { const int t = ceil_div(hw, 64); return t < 128 ? t : 128; }
 
+// the same with the result left in the bf16 NHWC layout (for the bf16 weight gradient of the 3-channel convolution, bf16_wgrad3.hip): no
+// transposition, a thread owns 8 channels of a pixel; same record layout
+__global__ __launch_bounds__(256) void prelu_bwd_bf16_nhwc_kernel(const __bf16* __restrict__ d1, const __bf16* __restrict__ d2, const __bf16* __restrict__ z,
+                                                                  const float* __restrict__ alpha, __bf16* __restrict__ dz, float* __restrict__ rec, int c,
+                                                                  int hw, int tiles) {
+    __shared__ float red[32][64];
+    const int img = blockIdx.y, tid = threadIdx.x;
+    const int ch = (tid & 7) * 8;
+    for (int c0 = 0; c0 < c; c0 += 64) {
+        float da[8], al[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            da[j] = 0.f;
+            al[j] = c0 + ch + j < c ? alpha[c0 + ch + j] : 0.f;
+        }
+        for (int t = blockIdx.x; t < tiles; t += gridDim.x) {
+            const int p0 = t * 64;
+#pragma unroll
+            for (int e = tid; e < 64 * 8; e += 256) {
+                const int pp = e >> 3;
+                if (c0 + ch < c && p0 + pp < hw) {
+                    const long o = ((long)img * hw + p0 + pp) * c + c0 + ch;
+                    const bf16x8 a = *(const bf16x8*)(d1 + o), zz = *(const bf16x8*)(z + o);
+                    bf16x8 b;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) b[j] = (__bf16)0.f;
+                    if (d2) b = *(const bf16x8*)(d2 + o);
+                    bf16x8 g;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float d = (float)a[j] + (float)b[j], zf = (float)zz[j];
+                        g[j] = (__bf16)(zf >= 0.f ? d : d * al[j]);
+                        da[j] += zf >= 0.f ? 0.f : d * zf;
+                    }
+                    *(bf16x8*)(dz + o) = g;
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) red[tid >> 3][ch + j] = da[j];
+        __syncthreads();
+        if (tid < 64 && c0 + tid < c) {
+            float s = 0.f;
+            for (int k = 0; k < 32; ++k) s += red[k][tid];
+            rec[((long)img * gridDim.x + blockIdx.x) * c + c0 + tid] = s;
+        }
+        __syncthreads();
+    }
+}
+
 int vcg_prelu_bwd_nhwc_bf16_records(int n, int hw) {
     if (n <= 0 || hw <= 0) return VCG_E_SHAPE;
     return n * prelu_bwd_gridx(hw);
@@ -1998,6 +2048,17 @@ int vcg_prelu_bwd_nhwc_bf16(const void* d1, const void* d2, const void* z, const
     if (c % 8) return VCG_E_UNSUPPORTED;
     prelu_bwd_bf16_to_f32_nchw_kernel<<<dim3(prelu_bwd_gridx(hw), n), 256, 0, stream>>>((const __bf16*)d1, (const __bf16*)d2, (const __bf16*)z, prelu_alpha,
                                                                                      dz_nchw, records, c, hw, ceil_div(hw, 64));
+    VCG_LAUNCH_CHECK();
+    return VCG_OK;
+}
+
+int vcg_prelu_bwd_nhwc_bf16_to_bf16(const void* d1, const void* d2, const void* z, const float* prelu_alpha, int n, int c, int hw, void* dz_nhwc,
+                                    float* records, hipStream_t stream) {
+    VCG_CHECK_PTR(d1); VCG_CHECK_PTR(z); VCG_CHECK_PTR(prelu_alpha); VCG_CHECK_PTR(dz_nhwc); VCG_CHECK_PTR(records);
+    if (n <= 0 || c <= 0 || hw <= 0 || n > 65535) return VCG_E_SHAPE;
+    if (c % 8) return VCG_E_UNSUPPORTED;
+    prelu_bwd_bf16_nhwc_kernel<<<dim3(prelu_bwd_gridx(hw), n), 256, 0, stream>>>((const __bf16*)d1, (const __bf16*)d2, (const __bf16*)z, prelu_alpha,
+                                                                              (__bf16*)dz_nhwc, records, c, hw, ceil_div(hw, 64));
     VCG_LAUNCH_CHECK();
     return VCG_OK;
 }

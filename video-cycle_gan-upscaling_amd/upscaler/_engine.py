@@ -849,7 +849,7 @@ class InitialConv9x9Bf16(Conv2D):
     fp32 NCHW frames to bf16 NHWC in one launch (vcg_conv9x9_from3_bf16_fwd[_train]: bf16 copies of frames and kernel as MFMA operands,
     fp32 accumulation).  In training the value in front of the PReLU is stored too; backward adds the gradients meeting at the output
     (trunk + long skip, both bf16 NHWC), applies the activation's derivative and the slope gradient in one pass
-    (vcg_prelu_bwd_nhwc_bf16) whose fp32 NCHW result feeds the fp32 weight-gradient kernel (the frames are fp32 NCHW).  Declares the
+    (vcg_prelu_bwd_nhwc_bf16_to_bf16) whose bf16 NHWC result feeds the bf16 weight-gradient kernel of the 3-channel layers (vcg_conv3ch_bf16_wgrad).  Declares the
     Conv2D's parameters; the PReLU slope belongs to the NormAct layer behind it (same names as the fp32 model)."""
 
     def __init__(self, name, cin, cout, k):
@@ -901,22 +901,36 @@ class InitialConv9x9Bf16(Conv2D):
         nrec = lib.vcg_prelu_bwd_nhwc_bf16_records(d.n, hw)
         L.check(min(nrec, 0), "vcg_prelu_bwd_nhwc_bf16_records")
         rec = rt.empty(nrec * self.cout)
+        gk, gb = self.ps.grad(self.name + "/kernel", which), self.ps.grad(self.name + "/bias", which)
+        need = lib.vcg_conv3ch_bf16_wgrad_workspace_bytes(ctypes.byref(d))
+        if need:
+            # dz stays bf16 NHWC: the weight gradient multiplies it as an MFMA operand (vcg_conv3ch_bf16_wgrad)
+            dz = torch.empty(d.n, d.h, d.w, self.cout, dtype=torch.bfloat16, device=rt.device)
+            L.check(lib.vcg_prelu_bwd_nhwc_bf16_to_bf16(d1.data_ptr(), _ptr(d2), z.data_ptr(), alpha.data_ptr(), d.n, self.cout, hw, dz.data_ptr(),
+                                                        rec.data_ptr(), rt.stream), "vcg_prelu_bwd_nhwc_bf16_to_bf16")
+            L.check(lib.vcg_sum_records(rec.data_ptr(), nrec, self.cout, 1.0, dalpha.data_ptr(), rt.stream), "vcg_sum_records[%s]" % self.name)
+            ws, wsn = rt.workspace(need)
+            with Timed(rt, tag and tag + "_wgrad"):
+                L.check(lib.vcg_conv3ch_bf16_wgrad(ctypes.byref(d), x.data_ptr(), dz.data_ptr(), gk.data_ptr(), gb.data_ptr(), ws, wsn, rt.stream),
+                        "vcg_conv3ch_bf16_wgrad[%s]" % self.name)
+            return
+        # odd widths: the fp32 weight-gradient kernel on the fp32 NCHW form of dz
         dz = rt.empty(d.n, self.cout, d.h, d.w)
         L.check(lib.vcg_prelu_bwd_nhwc_bf16(d1.data_ptr(), _ptr(d2), z.data_ptr(), alpha.data_ptr(), d.n, self.cout, hw, dz.data_ptr(),
                                             rec.data_ptr(), rt.stream), "vcg_prelu_bwd_nhwc_bf16")
         L.check(lib.vcg_sum_records(rec.data_ptr(), nrec, self.cout, 1.0, dalpha.data_ptr(), rt.stream), "vcg_sum_records[%s]" % self.name)
         ws, wsn = rt.workspace(lib.vcg_conv2d_wgrad_workspace_bytes(ctypes.byref(d)))
         with Timed(rt, tag and tag + "_wgrad"):
-            L.check(lib.vcg_conv2d_wgrad(ctypes.byref(d), x.data_ptr(), dz.data_ptr(), self.ps.grad(self.name + "/kernel", which).data_ptr(),
-                                         self.ps.grad(self.name + "/bias", which).data_ptr(), ws, wsn, rt.stream), "vcg_conv2d_wgrad[%s]" % self.name)
+            L.check(lib.vcg_conv2d_wgrad(ctypes.byref(d), x.data_ptr(), dz.data_ptr(), gk.data_ptr(), gb.data_ptr(), ws, wsn, rt.stream),
+                    "vcg_conv2d_wgrad[%s]" % self.name)
 
 
 class FirstConvBf16(Conv2D):
     """A critic's first layer -- Conv2D on the 3-channel fp32 NCHW frames -- writing bf16 NHWC directly (vcg_conv3ch_bf16_fwd: bf16 copies of
     frames and kernel as MFMA operands, fp32 accumulation, + bias [+ LeakyReLU]): simple_512 / thin_512 block 1 (3x3 'same', model.py:839;
     its BatchNormalization follows on bf16) and the PatchGAN's 4x4 stride-2 layer + LeakyReLU(0.2).  backward takes the bf16 NHWC gradient
-    IN FRONT of the activation (the next layer's data gradient applies the LeakyReLU mask: Conv2DBf16.backward(mask=...)), turns it into the
-    fp32 NCHW layout once and runs the fp32 weight / data gradient kernels on the fp32 frames."""
+    IN FRONT of the activation (the next layer's data gradient applies the LeakyReLU mask: Conv2DBf16.backward(mask=...)); weight gradient on
+    vcg_conv3ch_bf16_wgrad (frames and gradient as bf16 MFMA operands), data gradient on vcg_conv3ch_bf16_dgrad."""
 
     def __init__(self, name, cin, cout, k, stride=1, padding="same", act=L.ACT_NONE, alpha=0.0):
         if cin != 3 or cout % 64 or cout > 512 or (k, stride) not in ((3, 1), (4, 2)) or act not in (L.ACT_NONE, L.ACT_LRELU):
@@ -957,12 +971,19 @@ class FirstConvBf16(Conv2D):
         x, _, d = ctx
         dz32 = None
         if param_grads:
-            dz32 = from_bf16_nhwc(rt, dz)
-            ws, wsn = rt.workspace(rt.lib.vcg_conv2d_wgrad_workspace_bytes(ctypes.byref(d)))
-            with Timed(rt, tag and tag + "_wgrad"):
-                L.check(rt.lib.vcg_conv2d_wgrad(ctypes.byref(d), x.data_ptr(), dz32.data_ptr(), self.ps.grad(self.name + "/kernel", which).data_ptr(),
-                                                self.ps.grad(self.name + "/bias", which).data_ptr(), ws, wsn, rt.stream),
-                        "vcg_conv2d_wgrad[%s]" % self.name)
+            gk, gb = self.ps.grad(self.name + "/kernel", which), self.ps.grad(self.name + "/bias", which)
+            need = rt.lib.vcg_conv3ch_bf16_wgrad_workspace_bytes(ctypes.byref(d))
+            if need:
+                ws, wsn = rt.workspace(need)
+                with Timed(rt, tag and tag + "_wgrad"):
+                    L.check(rt.lib.vcg_conv3ch_bf16_wgrad(ctypes.byref(d), x.data_ptr(), dz.data_ptr(), gk.data_ptr(), gb.data_ptr(), ws, wsn, rt.stream),
+                            "vcg_conv3ch_bf16_wgrad[%s]" % self.name)
+            else:       # odd widths: the fp32 weight-gradient kernel on an fp32 NCHW copy of dz
+                dz32 = from_bf16_nhwc(rt, dz)
+                ws, wsn = rt.workspace(rt.lib.vcg_conv2d_wgrad_workspace_bytes(ctypes.byref(d)))
+                with Timed(rt, tag and tag + "_wgrad"):
+                    L.check(rt.lib.vcg_conv2d_wgrad(ctypes.byref(d), x.data_ptr(), dz32.data_ptr(), gk.data_ptr(), gb.data_ptr(), ws, wsn, rt.stream),
+                            "vcg_conv2d_wgrad[%s]" % self.name)
         if not need_dx:
             return None
         dx = rt.empty(d.n, self.cin, d.h, d.w)

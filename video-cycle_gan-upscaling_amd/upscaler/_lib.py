@@ -121,9 +121,12 @@ SIGNATURES = {
     "vcg_conv3ch_bf16_fwd": (c_int, [_D, _P, _P, _P, c_float, _P, _P]),
     "vcg_conv3ch_bf16_dgrad_workspace_bytes": (c_size_t, [_D]),
     "vcg_conv3ch_bf16_dgrad": (c_int, [_D, _P, _P, _P, _P, c_size_t, _P]),
+    "vcg_conv3ch_bf16_wgrad_workspace_bytes": (c_size_t, [_D]),
+    "vcg_conv3ch_bf16_wgrad": (c_int, [_D, _P, _P, _P, _P, _P, c_size_t, _P]),
     "vcg_conv9x9_from3_bf16_fwd_train": (c_int, [_D, _P, _P, _P, _P, _P, _P, _P]),
     "vcg_prelu_bwd_nhwc_bf16_records": (c_int, [c_int, c_int]),
     "vcg_prelu_bwd_nhwc_bf16": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P, _P, _P]),
+    "vcg_prelu_bwd_nhwc_bf16_to_bf16": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P, _P, _P]),
     "vcg_conv2d_cout1_nhwc_bf16_fwd": (c_int, [_D, _P, _P, _P, _P, _P]),
     "vcg_conv2d_cout1_nhwc_bf16_dgrad": (c_int, [_D, _P, _P, _P, _P]),
     "vcg_conv2d_cout1_nhwc_bf16_wgrad_workspace_bytes": (c_size_t, [_D]),
