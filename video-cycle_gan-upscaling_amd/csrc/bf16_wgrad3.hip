@@ -237,31 +237,33 @@ __global__ __launch_bounds__(256, 2) void wgrad3_bf16_kernel(W3Params p) {
     if (chalf == 0 && p.wsb) p.wsb[((((long)cob * p.grid + bx) * 2 + mrow) * 2 + (lane >> 5)) * 32 + (lane & 31)] = dbs;
 }
 
-// dW[tap][ci][co] (and db[co]) = sum over workgroups, in a fixed order, of the wave blocks.  block = 64 output elements x 16 record lanes
-// (eight records in flight per thread, then a fixed-order combine through LDS): one thread per element walking all 256 records was
-// latency-bound (59 / 83 us for the 4x4 / 9x9 layers against 24 / 42 us for the weight-gradient kernels themselves).
+// dW[tap][ci][co] (and db[co]) = sum over workgroups, in a fixed order, of the wave blocks.  block = 64 consecutive RAW dump elements x 16
+// record lanes (coalesced reads, eight records in flight per thread, fixed-order combine through LDS); the decoded (tap, ci, co) position
+// is only used for the single store.  The blocks past the weight dump sum the bias partials (two lane halves per record) the same way.
 template <int K>
 __global__ __launch_bounds__(1024) void wgrad3_reduce_kernel(const float* __restrict__ ws, const float* __restrict__ wsb, int grid, int cout,
                                                              float* __restrict__ dw, float* __restrict__ db) {
     constexpr int T = K * K, NT = (T + 7) / 8, NTW = (NT + 1) / 2, WAVE_FLOATS = NTW * 16 * 64;
     __shared__ float red[16][64];
     const int g = threadIdx.x >> 6, cl = threadIdx.x & 63;
-    const int idx = blockIdx.x * 64 + cl;
-    const int nw = T * 3 * cout;
-    const bool is_w = idx < nw, is_b = !is_w && db != nullptr && idx < nw + cout;
+    const int co_blocks = cout >> 6, nraw = co_blocks * 4 * WAVE_FLOATS;
+    const int r = blockIdx.x * 64 + cl;
+    const bool is_w = r < nraw;                                      // (block-uniform: nraw is a multiple of 64)
+    const int rb = r - nraw;                                         // bias: channel index
+    const bool is_b = !is_w && db != nullptr && rb < cout;
     const float* src = ws;
     long stride = 0;
-    int second = 0;                                                   // the bias partials come as two lane halves per record
+    int second = 0, cob = 0, wave = 0, off = 0;
     if (is_w) {
-        const int co = idx % cout, ci = (idx / cout) % 3, tap = idx / (3 * cout);
-        const int cob = co >> 6, mrow = (co >> 5) & 1, m = co & 31, nt = tap >> 3, chalf = nt / NTW, j = nt - chalf * NTW, col = (tap & 7) * 4 + ci;
-        // MFMA 32x32 accumulator layout: lane (col, hh) register e holds row m = 8*(e>>2) + 4*hh + (e&3)
-        const int hh = (m >> 2) & 1, e = ((m >> 3) << 2) | (m & 3), lane = hh * 32 + col;
-        src = ws + (((long)cob * grid) * 4 + (mrow + 2 * chalf)) * WAVE_FLOATS + (j * 16 + e) * 64 + lane;
+        cob = r / (4 * WAVE_FLOATS);
+        const int rem = r - cob * 4 * WAVE_FLOATS;
+        wave = rem / WAVE_FLOATS;
+        off = rem - wave * WAVE_FLOATS;
+        src = ws + (((long)cob * grid) * 4 + wave) * WAVE_FLOATS + off;
         stride = 4l * WAVE_FLOATS;
     } else if (is_b) {
-        const int co = idx - nw, cob = co >> 6, mrow = (co >> 5) & 1, m = co & 31;
-        src = wsb + ((((long)cob * grid) * 2 + mrow) * 2) * 32 + m;
+        const int bc = rb >> 6, mrow = (rb >> 5) & 1, m = rb & 31;
+        src = wsb + ((((long)bc * grid) * 2 + mrow) * 2) * 32 + m;
         stride = 128;
         second = 32;
     }
@@ -283,8 +285,15 @@ __global__ __launch_bounds__(1024) void wgrad3_reduce_kernel(const float* __rest
     float t = 0.f;
 #pragma unroll
     for (int i = 0; i < 16; ++i) t += red[i][cl];
-    if (is_w) dw[idx] = t;
-    else db[idx - nw] = t;
+    if (is_b) {
+        db[rb] = t;
+        return;
+    }
+    // raw offset -> column tile j of the wave, register e, lane l;  D[row][col]: row = (e&3) + 8*(e>>2) + 4*(l>>5), col = l&31 = (tap slot, ci)
+    const int l = off & 63, e = (off >> 6) & 15, j = off >> 10, mrow = wave & 1, chalf = wave >> 1;
+    const int m = (e & 3) + 8 * (e >> 2) + 4 * (l >> 5), col = l & 31, tap = 8 * (chalf * NTW + j) + (col >> 2), ci = col & 3;
+    const int co = cob * 64 + mrow * 32 + m;
+    if (tap < T && ci < 3) dw[(tap * 3 + ci) * cout + co] = t;
 }
 
 // fp32 NCHW frames [n][3][h][w] -> bf16 [n][h][w][4] (channel 3 = 0)
@@ -310,7 +319,7 @@ int launch_w3(const W3Params& p, float* dw, float* db, hipStream_t st) {
     }
     hipLaunchKernelGGL(kern, dim3(p.grid * p.co_blocks), dim3(256), C::NS * C::BUF, st, p);
     VCG_LAUNCH_CHECK();
-    const int total = K * K * 3 * p.cout + p.cout;
+    const int total = p.co_blocks * 4 * C::WAVE_FLOATS + p.cout;     // raw dump elements + bias channels
     hipLaunchKernelGGL(wgrad3_reduce_kernel<K>, dim3(ceil_div(total, 64)), dim3(1024), 0, st, (const float*)p.ws, (const float*)p.wsb, p.grid, p.cout, dw, db);
     VCG_LAUNCH_CHECK();
     return VCG_OK;

@@ -224,22 +224,36 @@ __global__ __launch_bounds__(W9_NTH, 1) void wgrad9x9_c256to3_bf16_kernel(W9Para
     }
 }
 
-// dW[tap][ci][co] = sum over workgroups (fixed order) of the wave blocks; thread = one output element
-__global__ __launch_bounds__(256) void wgrad9_reduce_kernel(const float* __restrict__ ws, int grid, float* __restrict__ dw) {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= 81 * 256 * 3) return;
-    const int co = idx % 3, ci = (idx / 3) % 256, tap = idx / 768;
-    const int mh = ci >> 7, wv = (ci >> 5) & 3, m = ci & 31, nt = tap >> 3, n = (tap & 7) * 4 + co;
-    // MFMA 32x32 accumulator layout: lane (n, hh) register e holds row m = 8*(e>>2) + 4*hh + (e&3)
-    const int hh = (m >> 2) & 1, e = ((m >> 3) << 2) | (m & 3), lane = hh * 32 + n;
-    const float* src = ws + (((long)mh * grid) * 4 + wv) * W9_WAVE_FLOATS + (nt * 16 + e) * 64 + lane;
-    float s4[4] = {0.f, 0.f, 0.f, 0.f};
-    int k = 0;
-    for (; k + 4 <= grid; k += 4)
+// dW[tap][ci][co] = sum over workgroups, in a fixed order, of the wave blocks.  block = 64 consecutive RAW dump elements x 16 record lanes
+// (coalesced reads, eight records in flight per thread, fixed-order combine through LDS); the decoded (tap, ci, co) position is only used
+// for the single store.  (One thread per OUTPUT element walking all records read scattered words one latency after the other: 47 us.)
+__global__ __launch_bounds__(1024) void wgrad9_reduce_kernel(const float* __restrict__ ws, int grid, float* __restrict__ dw) {
+    __shared__ float red[16][64];
+    const int g = threadIdx.x >> 6, cl = threadIdx.x & 63;
+    const int r = blockIdx.x * 64 + cl;                              // raw element: [channel half][row tile][W9_WAVE_FLOATS]
+    const int mh = r / (4 * W9_WAVE_FLOATS), rem = r - mh * 4 * W9_WAVE_FLOATS, mt = rem / W9_WAVE_FLOATS, off = rem - mt * W9_WAVE_FLOATS;
+    const float* src = ws + (((long)mh * grid) * 4 + mt) * W9_WAVE_FLOATS + off;
+    const long stride = 4l * W9_WAVE_FLOATS;
+    float s = 0.f;
+    int b = g;
+    for (; b + 16 * 7 < grid; b += 16 * 8) {
+        float v[8];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) s4[u] += src[(long)(k + u) * 4 * W9_WAVE_FLOATS];
-    for (; k < grid; ++k) s4[0] += src[(long)k * 4 * W9_WAVE_FLOATS];
-    dw[idx] = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+        for (int u = 0; u < 8; ++u) v[u] = src[(long)(b + 16 * u) * stride];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; b < grid; b += 16) s += src[(long)b * stride];
+    red[g][cl] = s;
+    __syncthreads();
+    if (g != 0) return;
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) t += red[i][cl];
+    // raw offset -> column tile nt, register e, lane l;  D[row][col]: row = (e&3) + 8*(e>>2) + 4*(l>>5), col = l&31 = (tap slot, co)
+    const int l = off & 63, e = (off >> 6) & 15, nt = off >> 10;
+    const int m = (e & 3) + 8 * (e >> 2) + 4 * (l >> 5), n = l & 31, tap = 8 * nt + (n >> 2), co = n & 3, ci = mh * 128 + mt * 32 + m;
+    if (tap < 81 && co < 3) dw[(tap * 256 + ci) * 3 + co] = t;
 }
 
 // dz fp32 NCHW [n][3][h][w] -> bf16 [n][h][w][4] (channel 3 = 0)
@@ -293,7 +307,8 @@ int vcg_conv9x9_to3_bf16_wgrad(const vcg_conv_desc* d, const void* x, const floa
     }
     wgrad9x9_c256to3_bf16_kernel<<<dim3(2 * p.grid), W9_NTH, W9_NS * W9_BUF, stream>>>(p);
     VCG_LAUNCH_CHECK();
-    wgrad9_reduce_kernel<<<(81 * 256 * 3 + 255) / 256, 256, 0, stream>>>((const float*)ws, p.grid, dw_hwio);
+    static_assert(W9_WAVE_FLOATS % 64 == 0, "wgrad9 reduce: 64 raw elements per block stay inside one wave block");
+    wgrad9_reduce_kernel<<<2 * 4 * W9_WAVE_FLOATS / 64, 1024, 0, stream>>>((const float*)ws, p.grid, dw_hwio);
     VCG_LAUNCH_CHECK();
     return VCG_OK;
 }
