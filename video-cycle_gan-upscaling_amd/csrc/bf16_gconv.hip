@@ -200,6 +200,10 @@ struct GlParams {
     float alpha, mask_slope;
     int isy, isx;           // input pixel of plane (py, px), plane coordinates (i, j): (isy*i + py, isx*j + px)
     int tiles_x, tiles_y, pairs, mgroups, nplanes;
+    // the S x S output phases of a strided layer's data gradient merged into ONE launch (phase = fastest index of the pair: the workgroups
+    // that read the same dy tile with the four tap sets run side by side); each phase has one plane pl[phase] and its own output placement
+    int nphases;
+    struct Phase { int ooy, oox, loh, low; } ph[4];
     float* stats;           // optional: [n][tiles_y * tiles_x][2][mch] sums and sums of squares of the stored (bf16-rounded) output per tile
     struct Plane {
         int py, px, dy0, dx0;     // parity; smallest tap offsets in plane coordinates: halo origin of a tile = (ly0 + dy0, lx0 + dx0)
@@ -207,7 +211,7 @@ struct GlParams {
     } pl[4];
 };
 
-struct GlSrc { int img, y0, x0, mg, ty, tx; };       // a (tile, output-channel group) pair: image, halo origin, group, tile coordinates
+struct GlSrc { int img, y0, x0, mg, ty, tx, ph; };   // a (tile, output-channel group, phase) pair: image, halo origin, group, tile coordinates, phase
 
 __device__ __forceinline__ void gl_barrier() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
@@ -249,16 +253,17 @@ __global__ __launch_bounds__(HALF ? 512 : 256, 1) void gconv_lds_bf16_kernel(con
     }
     // halo slot of this lane in DMA round k: pixel (row, col), chunk position -- advanced incrementally (32 pixels per round)
     auto decode = [&](int pair) {
-        const int mg = pair % p.mgroups, t = pair / p.mgroups;
+        const int ph = pair % p.nphases, pq = pair / p.nphases;
+        const int mg = pq % p.mgroups, t = pq / p.mgroups;
         const int tx = t % p.tiles_x, t2 = t / p.tiles_x, ty = t2 % p.tiles_y, img = t2 / p.tiles_y;
-        return GlSrc{img, ty * GL_TR, tx * GL_TC, mg, ty, tx};
+        return GlSrc{img, ty * GL_TR, tx * GL_TC, mg, ty, tx, ph};
     };
     const int cpp = p.kch >> 6;                                  // chunks per plane
     const int dtid = LOADERS ? tid - 256 : tid, dwv = LOADERS ? wv - 4 : wv;     // the staging thread / wave index (loader waves: 4..7)
     auto dma = [&](const GlSrc& sc, int c, int buf, int k, bool live) {
         const int sl = k * 256 + dtid, P = sl >> 3, row = P / HC, col = P - row * HC;
         const int cs = (sl & 7) ^ ((col >> 1) & 7);                                // stored chunk (sl & 7) holds source chunk cs
-        const int pli = c / cpp, cc = c - pli * cpp;
+        const int cc = c % cpp, pli = sc.ph + c / cpp;            // (a merged phase has one plane: c / cpp == 0)
         const int iy = p.isy * (sc.y0 + p.pl[pli].dy0 + row) + p.pl[pli].py, ix = p.isx * (sc.x0 + p.pl[pli].dx0 + col) + p.pl[pli].px;
         const bool ok = live && sl < CH16 && (unsigned)iy < (unsigned)p.ih && (unsigned)ix < (unsigned)p.iw;
         unsigned off = ((unsigned)(iy * p.iw + ix) * (unsigned)p.kch + (unsigned)(cc * 64)) * 2u + (unsigned)(cs * 16);      // < 4 GiB: unsigned arithmetic
@@ -337,7 +342,7 @@ __global__ __launch_bounds__(HALF ? 512 : 256, 1) void gconv_lds_bf16_kernel(con
         const int nc = last_chunk ? 0 : c + 1;
         const unsigned char* xb = smem + buf * BUF;
         const int mtile = cur.mg * (HALF ? 2 : 4) + mw;
-        const int pli = c / cpp, cc = c - pli * cpp;
+        const int cc = c % cpp, pli = cur.ph + c / cpp;
 
         bf16x8 fb[2][TRW + SP], a[2][SP + 1];
         auto frag = [&](int g, int b) {
@@ -375,7 +380,7 @@ __global__ __launch_bounds__(HALF ? 512 : 256, 1) void gconv_lds_bf16_kernel(con
             const float slope = p.act == VCG_ACT_LRELU ? p.alpha : 1.f;
             const vcg_rsrc ry = make_rsrc((unsigned char*)p.y + cur.img * img_out, (unsigned long)img_out);
             const vcg_rsrc rm = make_rsrc((const unsigned char*)p.mask_src + cur.img * img_out, (unsigned long)(p.mask_src ? img_out : 0));
-            const int lx = cur.tx * GL_TC + r, ox = lx * p.osx + p.oox;
+            const int lx = cur.tx * GL_TC + r, ox = lx * p.osx + p.ph[cur.ph].oox;
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 const int co = mtile * 32 + 16 * q + 8 * hh;
@@ -384,8 +389,8 @@ __global__ __launch_bounds__(HALF ? 512 : 256, 1) void gconv_lds_bf16_kernel(con
                 for (int j = 0; j < 8; ++j) bs[j] = p.bias && mtile < p.mblocks ? p.bias[co + j] : 0.f;
 #pragma unroll
                 for (int n = 0; n < TRW; ++n) {
-                    const int ly = cur.ty * GL_TR + r0 + n, oy = ly * p.osy + p.ooy;
-                    const bool ok = ly < p.loh && lx < p.low && oy < p.oh && ox < p.ow && mtile < p.mblocks;
+                    const int ly = cur.ty * GL_TR + r0 + n, oy = ly * p.osy + p.ph[cur.ph].ooy;
+                    const bool ok = ly < p.ph[cur.ph].loh && lx < p.ph[cur.ph].low && oy < p.oh && ox < p.ow && mtile < p.mblocks;
                     unsigned off = ((unsigned)(oy * p.ow + ox) * (unsigned)p.mch + (unsigned)co) * 2u;
                     asm volatile("" : "+v"(off));
                     off = ok ? off : VCG_OOB;
@@ -490,7 +495,7 @@ int launch_gconv_lds_sp(const GlParams& q, int grid, hipStream_t st) {
 
 // the LDS-tiled kernel where it applies (input stride 1 or 2, 64-channel input chunks, >= 64 output channels, the taps of a parity plane
 // inside a 5x5 box, images below 4 GiB, enough tiles to fill the chip); VCG_GCONV_LDS=0 forces the streaming kernel (A/B aid)
-bool plan_gconv_lds(const GcParams& p, GlParams& q, int& spe_out, bool& half_out) {
+bool plan_gconv_lds(const GcParams& p, GlParams& q, int& spe_out, bool& half_out, int force_spe = 0, bool check_pairs = true) {
     static const bool off = getenv("VCG_GCONV_LDS") && atoi(getenv("VCG_GCONV_LDS")) == 0;
     if (off || p.isy != p.isx || p.isy < 1 || p.isy > 2 || p.kch % 64 || p.mblocks < 2 || p.ntaps < 1) return false;
     if ((long)p.ih * p.iw * p.kch * 2 > 0xFFFFFFE0l || (long)p.oh * p.ow * p.mch * 2 > 0xFFFFFFE0l) return false;
@@ -516,7 +521,8 @@ bool plan_gconv_lds(const GcParams& p, GlParams& q, int& spe_out, bool& half_out
             sp = span > sp ? span : sp;
         }
     if (sp > 4 || q.nplanes < 1) return false;
-    const int spe = sp < 1 ? 1 : sp;
+    if (force_spe && sp > force_spe) return false;
+    const int spe = force_spe ? force_spe : (sp < 1 ? 1 : sp);
     for (int k = 0; k < q.nplanes; ++k) {
         GlParams::Plane& pl = q.pl[k];
         for (int i = 0; i < 25; ++i) pl.wt[i] = -1;
@@ -534,9 +540,57 @@ bool plan_gconv_lds(const GcParams& p, GlParams& q, int& spe_out, bool& half_out
     half_out = p.mblocks == 2 && p.stats == nullptr && spe <= 3;     // 64 output channels: waves = 2 channel blocks x 2 row halves (+ loaders, three stages)
     q.mgroups = half_out ? 1 : (p.mblocks + 3) / 4;
     const long pairs = (long)p.n * q.tiles_x * q.tiles_y * q.mgroups;
-    if (pairs < 64 || pairs > 0x7fffffffL) return false;        // too little work for 256 one-workgroup CUs: the streaming kernel's small tiles fill the chip better
+    if ((check_pairs && pairs < 64) || pairs > 0x7fffffffL) return false;        // too little work for 256 one-workgroup CUs: the streaming kernel's small tiles fill the chip better
     q.pairs = (int)pairs;
+    q.nphases = 1;
+    q.ph[0] = GlParams::Phase{p.ooy, p.oox, p.loh, p.low};
     spe_out = spe;
+    return true;
+}
+
+int launch_gconv_lds(const GlParams& q, int spe, bool half, hipStream_t st) {
+    const int grid = q.pairs < 256 ? q.pairs : 256;
+    switch (spe) {
+        case 1: return half ? launch_gconv_lds_sp<1, true>(q, grid, st) : launch_gconv_lds_sp<1, false>(q, grid, st);
+        case 2: return half ? launch_gconv_lds_sp<2, true>(q, grid, st) : launch_gconv_lds_sp<2, false>(q, grid, st);
+        case 3: return half ? launch_gconv_lds_sp<3, true>(q, grid, st) : launch_gconv_lds_sp<3, false>(q, grid, st);
+        default: return half ? launch_gconv_lds_sp<4, true>(q, grid, st) : launch_gconv_lds_sp<4, false>(q, grid, st);
+    }
+}
+
+// the np (= 4: stride 2) output phases of a data gradient as ONE launch of the LDS-tiled kernel: each phase on its own was a launch of a
+// quarter of the tiles (PatchGAN block 3 at C3's shard: 128 tiles for 256 CUs, four times in a row), and the four tap sets of a dy tile
+// were fetched by four launches.  false: some phase does not fit the kernel (the caller launches the phases one by one)
+bool try_gconv_lds_phases(const GcParams* ps, int np, hipStream_t st, int* rc) {
+    if (np < 2 || np > 4) return false;
+    GlParams q[4];
+    int spe = 1;
+    bool half = false;
+    for (int i = 0; i < np; ++i) {
+        int si = 1;
+        bool hi = false;
+        if (ps[i].loh <= 0 || ps[i].low <= 0 || !plan_gconv_lds(ps[i], q[i], si, hi, 0, false) || q[i].nplanes != 1) return false;
+        spe = si > spe ? si : spe;
+    }
+    for (int i = 0; i < np; ++i) {
+        int si = 1;
+        bool hi = false;
+        if (!plan_gconv_lds(ps[i], q[i], si, hi, spe, false) || si != spe) return false;
+        if (i == 0) half = hi;
+        else if (hi != half) return false;
+    }
+    GlParams m = q[0];
+    m.nphases = np;
+    for (int i = 0; i < np; ++i) {
+        m.pl[i] = q[i].pl[0];
+        m.ph[i] = q[i].ph[0];
+        m.tiles_x = q[i].tiles_x > m.tiles_x ? q[i].tiles_x : m.tiles_x;
+        m.tiles_y = q[i].tiles_y > m.tiles_y ? q[i].tiles_y : m.tiles_y;
+    }
+    const long pairs = (long)m.n * m.tiles_x * m.tiles_y * m.mgroups * np;
+    if (pairs < 64 || pairs > 0x7fffffffL) return false;
+    m.pairs = (int)pairs;
+    *rc = launch_gconv_lds(m, spe, half, st);
     return true;
 }
 
@@ -545,13 +599,7 @@ bool try_gconv_lds(const GcParams& p, hipStream_t st, int* rc) {
     int spe = 1;
     bool half = false;
     if (!plan_gconv_lds(p, q, spe, half)) return false;
-    const int grid = q.pairs < 256 ? q.pairs : 256;
-    switch (spe) {
-        case 1: *rc = half ? launch_gconv_lds_sp<1, true>(q, grid, st) : launch_gconv_lds_sp<1, false>(q, grid, st); break;
-        case 2: *rc = half ? launch_gconv_lds_sp<2, true>(q, grid, st) : launch_gconv_lds_sp<2, false>(q, grid, st); break;
-        case 3: *rc = half ? launch_gconv_lds_sp<3, true>(q, grid, st) : launch_gconv_lds_sp<3, false>(q, grid, st); break;
-        default: *rc = half ? launch_gconv_lds_sp<4, true>(q, grid, st) : launch_gconv_lds_sp<4, false>(q, grid, st); break;
-    }
+    *rc = launch_gconv_lds(q, spe, half, st);
     return true;
 }
 
@@ -704,7 +752,11 @@ int vcg_conv2d_nhwc_bf16_dgrad(const vcg_conv_desc* d, const void* dy, const voi
     const int S = d->stride;
     p.osy = p.osx = S;
     // dx[iy][ix] = sum over taps with (iy + pad - ky) % S == 0 of W[ky][kx]^T dy[(iy + pad - ky)/S][(ix + pad - kx)/S]:
-    // one launch per output phase (iy % S, ix % S) with that phase's taps
+    // one problem per output phase (iy % S, ix % S) with that phase's taps -- the four of a stride-2 layer as ONE launch where the LDS-tiled
+    // kernel serves them all, else one launch per phase
+    GcParams phases[9];
+    int np = 0;
+    bool all = true;
     for (int py = 0; py < S; ++py)
         for (int px = 0; px < S; ++px) {
             p.ooy = py; p.oox = px;
@@ -719,14 +771,23 @@ int vcg_conv2d_nhwc_bf16_dgrad(const vcg_conv_desc* d, const void* dy, const voi
                     p.taps[p.ntaps++] = GcTap{(short)((py + d->pad_top - ky) / S), (short)((px + d->pad_left - kx) / S), (short)(ky * d->kw + kx), 0};
                 }
             }
-            if (p.loh <= 0 || p.low <= 0) continue;
+            if (p.loh <= 0 || p.low <= 0) { all = false; continue; }
             if (p.ntaps == 0) {   // a phase no tap reaches (k < S): its pixels are zero -- one zero tap keeps the kernel's store path
                 p.taps[0] = GcTap{(short)-30000, (short)-30000, 0, 0};
                 p.ntaps = 1;
+                all = false;
             }
-            rc = launch_gconv(p, stream);
-            if (rc) return rc;
+            phases[np++] = p;
         }
+    static const bool merge_off = getenv("VCG_GCONV_MERGE_PHASES") && atoi(getenv("VCG_GCONV_MERGE_PHASES")) == 0;      // A/B aid
+    if (all && np == 4 && !merge_off) {
+        int lrc = VCG_OK;
+        if (try_gconv_lds_phases(phases, np, stream, &lrc)) return lrc;
+    }
+    for (int i = 0; i < np; ++i) {
+        rc = launch_gconv(phases[i], stream);
+        if (rc) return rc;
+    }
     return VCG_OK;
 }
 
