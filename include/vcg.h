@@ -415,6 +415,9 @@ int vcg_conv9x9_to3_bf16_wgrad(const vcg_conv_desc* d, const void* x, const floa
  * (a Conv2DTranspose kernel (kh,kw,out,in) is a Conv2D kernel with the roles of in / out exchanged.) */
 size_t vcg_conv_frag_bf16_bytes(int taps, int mdim, int kdim);
 int vcg_pack_conv_frag_bf16(const float* w, int taps, int mdim, int kdim, int mode, void* out, hipStream_t stream);
+/* both copies of one Keras (kh,kw,in,out) kernel in one launch: out_fwd = mode 0 with (mdim, kdim) = (cout, cin), out_dgrad = mode 1 with
+ * (mdim, kdim) = (cin, cout); cin, cout multiples of 32 */
+int vcg_pack_conv_frag_bf16_pair(const float* w, int32_t taps, int32_t cin, int32_t cout, void* out_fwd, void* out_dgrad, hipStream_t stream);
 /* y = act(conv(x) + bias), x / y bf16 NHWC, bias fp32 [cout] or NULL, act VCG_ACT_NONE / VCG_ACT_LRELU */
 int vcg_conv2d_nhwc_bf16_fwd(const vcg_conv_desc* d, const void* x, const void* wfrag, const float* bias, int act, float act_alpha,
                              void* y, hipStream_t stream);

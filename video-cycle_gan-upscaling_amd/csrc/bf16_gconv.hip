@@ -469,6 +469,27 @@ __global__ void pack_frag_kernel(const float* __restrict__ w, __bf16* __restrict
     }
 }
 
+// both operand copies of one Keras (kh,kw,in,out) kernel in one launch: out_fwd = mode 0 with (mdim, kdim) = (cout, cin), out_dgrad = mode 1 with
+// (mdim, kdim) = (cin, cout)
+__global__ void pack_frag_pair_kernel(const float* __restrict__ w, __bf16* __restrict__ out_fwd, __bf16* __restrict__ out_dgrad, int taps, int cin, int cout) {
+    const long total = (long)taps * cin * cout;
+    for (long i2 = blockIdx.x * (long)blockDim.x + threadIdx.x; i2 < 2 * total; i2 += (long)gridDim.x * blockDim.x) {
+        const int mode = i2 >= total;
+        const long idx = mode ? i2 - total : i2;
+        const int mdim = mode ? cin : cout, kdim = mode ? cout : cin;
+        const int ksteps = kdim >> 4, mblocks = mdim >> 5;
+        const int j = (int)(idx & 7), lane = (int)((idx >> 3) & 63);
+        long q = idx >> 9;
+        const int mb = (int)(q % mblocks); q /= mblocks;
+        const int ks = (int)(q % ksteps);
+        const int t = (int)(q / ksteps);
+        const int m = mb * 32 + (lane & 31), k = ks * 16 + 8 * (lane >> 5) + j;
+        // forward: W(m = out, k = in) = w[(t*cin + k)*cout + m];  data gradient: W(m = in, k = out) = w[(t*cin + m)*cout + k]
+        const float v = mode == 0 ? w[((long)t * cin + k) * cout + m] : w[((long)t * cin + m) * cout + k];
+        (mode ? out_dgrad : out_fwd)[idx] = (__bf16)v;
+    }
+}
+
 __global__ void bf16_to_f32_kernel(const __bf16* __restrict__ x, float* __restrict__ y, size_t count) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i < count) y[i] = (float)x[i];
@@ -646,6 +667,16 @@ int vcg_pack_conv_frag_bf16(const float* w, int taps, int mdim, int kdim, int mo
     const long total = (long)taps * mdim * kdim;
     hipLaunchKernelGGL(pack_frag_kernel, dim3((unsigned)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256)), dim3(256), 0, stream, w,
                        (__bf16*)out, taps, mdim, kdim, mode);
+    VCG_LAUNCH_CHECK();
+    return VCG_OK;
+}
+
+int vcg_pack_conv_frag_bf16_pair(const float* w, int taps, int cin, int cout, void* out_fwd, void* out_dgrad, hipStream_t stream) {
+    VCG_CHECK_PTR(w); VCG_CHECK_PTR(out_fwd); VCG_CHECK_PTR(out_dgrad);
+    if (taps <= 0 || cin <= 0 || cout <= 0 || cin % 32 || cout % 32) return VCG_E_UNSUPPORTED;
+    const long total = 2l * taps * cin * cout;
+    hipLaunchKernelGGL(pack_frag_pair_kernel, dim3((unsigned)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256)), dim3(256), 0, stream, w,
+                       (__bf16*)out_fwd, (__bf16*)out_dgrad, taps, cin, cout);
     VCG_LAUNCH_CHECK();
     return VCG_OK;
 }

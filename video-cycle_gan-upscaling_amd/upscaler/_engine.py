@@ -787,8 +787,7 @@ class Conv2DBf16(Conv2D):
             self._wd = torch.empty(t * self.cin * self.cout, dtype=torch.bfloat16, device=rt.device)
         if not self._pvalid:
             w = self.ps[self.name + "/kernel"].data_ptr()
-            L.check(rt.lib.vcg_pack_conv_frag_bf16(w, t, self.cout, self.cin, 0, self._wf.data_ptr(), rt.stream), "pack fwd")
-            L.check(rt.lib.vcg_pack_conv_frag_bf16(w, t, self.cin, self.cout, 1, self._wd.data_ptr(), rt.stream), "pack dgrad")
+            L.check(rt.lib.vcg_pack_conv_frag_bf16_pair(w, t, self.cin, self.cout, self._wf.data_ptr(), self._wd.data_ptr(), rt.stream), "pack fwd + dgrad")
             self._pvalid = True
         return self._wf, self._wd
 

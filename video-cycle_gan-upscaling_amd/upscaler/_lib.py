@@ -146,6 +146,7 @@ SIGNATURES = {
     # generic bf16 NHWC convolution
     "vcg_conv_frag_bf16_bytes": (c_size_t, [c_int, c_int, c_int]),
     "vcg_pack_conv_frag_bf16": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P]),
+    "vcg_pack_conv_frag_bf16_pair": (c_int, [_P, c_int, c_int, c_int, _P, _P, _P]),
     "vcg_conv2d_nhwc_bf16_fwd": (c_int, [_D, _P, _P, _P, c_int, c_float, _P, _P]),
     "vcg_conv2d_nhwc_bf16_stats_records": (c_int, [_D, c_int]),
     "vcg_conv2d_nhwc_bf16_fwd_stats": (c_int, [_D, _P, _P, _P, _P, _P, _P]),
