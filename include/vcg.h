@@ -70,6 +70,14 @@ const char* vcg_error_string(int code);
  *      :839-871 / :904-936 (discriminators), :65 (downsampling_block) -------------------------- */
 int vcg_conv2d_fwd(const vcg_conv_desc* d, const float* x, const float* w_hwio, float* y,
                    const vcg_epilogue* ep, vcg_stream_t stream);
+/* vcg_conv2d_fwd (+ bias, no activation) whose epilogue also leaves the statistics of the BatchNormalization / instance norm that follows
+ * (upscaling/upscaler/model.py:19-25, 284, 840): per output tile and channel the sum of (y - bias) and of its square, stats fp32
+ * [n][records per image][2][cout] with records = vcg_conv2d_stats_records(d, stats_mode) (stats_mode: 1 = VCG_STATS_BATCH -> n * tiles,
+ * 2 = VCG_STATS_INSTANCE -> tiles per image); feed them to vcg_norm_finalize_partials_shifted(kshift = bias).  3x3 / 4x4, stride 1-2, more than
+ * 3 input channels; a negative record count / VCG_E_UNSUPPORTED otherwise (run vcg_norm_stats on the output). */
+int vcg_conv2d_stats_records(const vcg_conv_desc* d, int stats_mode);
+int vcg_conv2d_fwd_stats(const vcg_conv_desc* d, const float* x, const float* w_hwio, const float* bias, float* y, float* stats,
+                         vcg_stream_t stream);
 /* dx = dL/dx given dy; `residual` (optional, shape of dx) is added: dx = dgrad + residual */
 int vcg_conv2d_dgrad(const vcg_conv_desc* d, const float* dy, const float* w_hwio, const float* w_hwoi,
                      float* dx, const float* residual, vcg_stream_t stream);
@@ -121,6 +129,11 @@ int vcg_bn_fold_batch(const float* const* bias, const float* const* moving_mean,
 int vcg_norm_finalize_partials(const float* part, int nrec, int groups, int c, double count, const float* gamma, const float* beta,
                                float eps, float* mean, float* scale, float* shift, float* invstd, float* moving_mean,
                                float* moving_var, float momentum, int unbiased_count, vcg_stream_t stream);
+/* the same for records that hold sums of (x - kshift[ch]) and of its square (vcg_conv2d_fwd_stats: kshift = the convolution's bias): the
+ * variance is that of the shifted values, the mean gets the shift back */
+int vcg_norm_finalize_partials_shifted(const float* part, int nrec, int groups, int c, double count, const float* kshift, const float* gamma,
+                                       const float* beta, float eps, float* mean, float* scale, float* shift, float* invstd, float* moving_mean,
+                                       float* moving_var, float momentum, int unbiased_count, vcg_stream_t stream);
 /* y = act(x*scale + shift) + residual ; scale/shift indexed [c] (rows==1) or [n*c] */
 int vcg_norm_act_fwd(const float* x, int n, int c, int hw, const float* scale, const float* shift,
                      int per_sample, int act, float act_alpha, const float* prelu_alpha,

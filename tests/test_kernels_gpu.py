@@ -461,3 +461,51 @@ def test_dropout_is_tf_nn_dropout_given_the_mask(rt):
     assert int(step.item()) == 2
     both = float((outs[0] & outs[1]).float().mean())
     assert abs(both - 0.81) < 3e-3                                            # the two steps' masks are independent
+
+
+STATS_EPILOGUE_CASES = [
+    # cin, cout, k, stride, padding, n, h, w, instance
+    (64, 64, 3, 1, "same", 2, 64, 128, False),       # the generator trunk's layer on 64-column tiles (two MFMA x-tiles per wave)
+    (64, 64, 3, 1, "same", 3, 37, 45, False),        # ragged rows and columns: the pixels past the image must not count
+    (64, 64, 3, 1, "same", 2, 19, 23, True),         # instance norm: records per image, 32-column tiles
+    (64, 128, 4, 2, 1, 2, 66, 50, False),            # PatchGAN block 2 (4x4 stride 2), two output-channel blocks
+    (128, 256, 4, 1, 1, 2, 20, 21, False),           # PatchGAN block 4's kernel (4x4 stride 1), large bias against a small spread
+    (64, 96, 3, 2, "same", 2, 31, 33, True),         # a ragged channel block (96 = 64 + 32), stride 2
+]
+
+
+@pytest.mark.parametrize("cin,cout,k,stride,padding,n,h,w,instance", STATS_EPILOGUE_CASES)
+def test_conv2d_stats_epilogue_matches_the_statistics_pass(rt, cin, cout, k, stride, padding, n, h, w, instance):
+    """vcg_conv2d_fwd_stats + vcg_norm_finalize_partials_shifted (the statistics of the normalisation behind a convolution from its epilogue)
+    against the fp64 statistics of the layer's output, and NormAct.forward(stats=...) against the separate statistics pass: same output, same
+    moving averages."""
+    from oracle import keras_ops as K
+    from upscaler import _engine as E, _lib as L
+    conv = E.Conv2D("c", cin, cout, k, stride, padding)
+    ps, w64 = _standalone(rt, conv, seed=cin + cout + h)
+    ps.set_weights({"c/bias": (np.random.RandomState(h).uniform(-3.0, 3.0, cout)).astype(np.float32)})       # |mean| >> spread for some channels
+    norm = E.NormAct("nm", cout, "instance" if instance else "batch", L.ACT_PRELU, 0.0, prelu_name="pr")
+    norm2 = E.NormAct("nm", cout, "instance" if instance else "batch", L.ACT_PRELU, 0.0, prelu_name="pr")
+    psn, _ = _standalone(rt, norm, seed=3)
+    psn2, _ = _standalone(rt, norm2, seed=3)
+    g = torch.Generator().manual_seed(h * 100 + w)
+    x = torch.randn(n, cin, h, w, generator=g).to(rt.device)
+    y, _, st = conv.forward_stats(x, instance)
+    assert st is not None, "this shape must be served by the statistics epilogue"
+    y_ref, _ = conv.forward(x)
+    assert torch.equal(y, y_ref)
+    out, ctx = norm.forward(y, True, stats=st)
+    out2, ctx2 = norm2.forward(y_ref, True)
+    yd = y_ref.double().cpu()
+    dims = (2, 3) if instance else (0, 2, 3)
+    mean64, var64 = yd.mean(dims), yd.var(dims, unbiased=False)
+    mean, invstd = ctx[1]
+    e_mean = float(((mean.cpu().double().reshape(mean64.shape) - mean64).abs() / (var64.sqrt() + 1e-6)).max())
+    e_is = rel_err(invstd.cpu().double().reshape(var64.shape), 1.0 / torch.sqrt(var64 + (1e-5 if instance else 1e-3)))
+    e_out = rel_err(out, out2)
+    report("fp32 conv stats epilogue %d->%d k%d s%d n=%d %dx%d %s: mean (in sigmas)=%.2e invstd=%.2e out vs stats pass=%.2e"
+           % (cin, cout, k, stride, n, h, w, "instance" if instance else "batch", e_mean, e_is, e_out))
+    assert e_mean < 1e-5 and e_is < 1e-5 and e_out < 1e-5
+    if not instance:
+        for nm in ("nm/moving_mean", "nm/moving_variance"):
+            assert rel_err(psn[nm], psn2[nm]) < 1e-5

@@ -5,7 +5,7 @@
 
 int vcg_internal_conv(const float* x, const float* w, float* y, int n, int cin, int h, int wd, int cout, int oh,
                       int ow, int kh, int kw, int stride, int pad_top, int pad_left, int flip, const vcg_epilogue* ep,
-                      int smallm, int ws_t, int ws_m, int ws_k, hipStream_t st);
+                      int smallm, int ws_t, int ws_m, int ws_k, hipStream_t st, float* stats = nullptr);
 int vcg_internal_convt(const float* x, const float* w, float* y, int n, int cin, int h, int wd, int cout, int oh,
                        int ow, int k, int cby, int cbx, const vcg_epilogue* ep, hipStream_t st);
 size_t vcg_internal_wgrad_ws(int n, int mtot, int ah, int aw, int jctot, int kh, int kw, int S);
@@ -60,6 +60,47 @@ int vcg_conv2d_fwd(const vcg_conv_desc* d, const float* x, const float* w_hwio, 
     return vcg_internal_conv(x, w_hwio, y, d->n, d->cin, d->h, d->w, d->cout, d->oh, d->ow, d->kh, d->kw, d->stride,
                              d->pad_top, d->pad_left, 0, ep, sm ? 1 : 0, d->cin * d->cout, 1, d->cout,
                              (hipStream_t)stream);
+}
+
+// the tile grid of conv_fwd_kernel for this layer (conv_fwd.hip: 8 output rows x 32 or 64 columns per workgroup)
+static bool conv_stats_tiles(const vcg_conv_desc* d, int* tiles_per_image) {
+    const bool k3 = d->kh == 3 && d->kw == 3, k4 = d->kh == 4 && d->kw == 4;
+    if (!(k3 || k4) || d->stride > 2 || d->cin <= 3) return false;
+    const bool sm = use_smallm(d->cout, d->kh, d->kw, d->stride);
+    if (sm) return false;
+    const int xt = (k3 && d->stride == 1 && d->ow > 32) ? 2 : 1;
+    *tiles_per_image = ceil_div(d->ow, 32 * xt) * ceil_div(d->oh, 8);
+    return true;
+}
+
+// records per group (image, or the whole batch) that vcg_conv2d_fwd_stats writes for this layer; a negative VCG_E_* when the layer's kernel
+// has no statistics epilogue (run vcg_norm_stats on the output)
+int vcg_conv2d_stats_records(const vcg_conv_desc* d, int stats_mode) {
+    int rc = check_desc(d);
+    if (rc) return rc;
+    int tpi = 0;
+    if (!conv_stats_tiles(d, &tpi) || (stats_mode != VCG_STATS_BATCH && stats_mode != VCG_STATS_INSTANCE)) return VCG_E_UNSUPPORTED;
+    const long all = (long)tpi * d->n;
+    if (all > 0x3fffffffL) return VCG_E_UNSUPPORTED;
+    return (int)(stats_mode == VCG_STATS_INSTANCE ? tpi : all);
+}
+
+// vcg_conv2d_fwd (bias, no activation) that also leaves, per output tile, the per-channel sum of (y - bias) and of its square:
+// stats fp32 [n][tiles per image][2][cout] -- read by vcg_norm_finalize_partials_shifted(kshift = bias) as [1][n * tiles] (batch statistics)
+// or [n][tiles] (instance norm).  The statistics pass of the normalisation behind the layer (model.py:20, 23, 284, 840) is gone.
+int vcg_conv2d_fwd_stats(const vcg_conv_desc* d, const float* x, const float* w_hwio, const float* bias, float* y, float* stats,
+                         vcg_stream_t stream) {
+    int rc = check_desc(d);
+    if (rc) return rc;
+    VCG_CHECK_PTR(x); VCG_CHECK_PTR(w_hwio); VCG_CHECK_PTR(y); VCG_CHECK_PTR(stats);
+    if ((d->oh - 1) * d->stride - d->pad_top >= d->h || (d->ow - 1) * d->stride - d->pad_left >= d->w) return VCG_E_SHAPE;
+    int tpi = 0;
+    if (!conv_stats_tiles(d, &tpi)) return VCG_E_UNSUPPORTED;
+    vcg_epilogue ep{};
+    ep.bias = bias;
+    ep.act = VCG_ACT_NONE;
+    return vcg_internal_conv(x, w_hwio, y, d->n, d->cin, d->h, d->w, d->cout, d->oh, d->ow, d->kh, d->kw, d->stride, d->pad_top, d->pad_left, 0,
+                             &ep, 0, d->cin * d->cout, 1, d->cout, (hipStream_t)stream, stats);
 }
 
 int vcg_conv2d_dgrad(const vcg_conv_desc* d, const float* dy, const float* w_hwio, const float* w_hwoi, float* dx,

@@ -34,6 +34,7 @@ struct ConvParams {
     int flip;
     // small-M kernel only: weight element (mch, kc, tap) at w[tap*ws_t + mch*ws_m + kc*ws_k]
     int ws_t, ws_m, ws_k;
+    float* stats;          // conv_fwd_kernel<..., STATS>: [n * tiles_y * tiles_x][2][cout] per-tile sums of the accumulators and of their squares
 };
 
 template <int KH, int KW, int S, int CK, int XT>
@@ -111,7 +112,48 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
     }
 }
 
-template <int KH, int KW, int S, int CK, int XT>
+// STATS epilogue: for the BatchNormalization / instance norm behind the convolution (model.py:19-25, 840) the workgroup also leaves, per output
+// channel, the sum of its tile's accumulators and of their squares -- the output minus the bias: a shift that keeps E[d^2] - E[d]^2 from
+// cancelling -- as one record per tile; vcg_norm_finalize_partials_shifted sums the records in a fixed order.  The statistics pass over the
+// output (one more read of the tensor, two more launches per normalisation) is gone.  A lane's 32 (channel) x 2 partial sums are
+// reduce-scattered over the 32 lanes of its half-wave, the four waves (row pairs) meet in LDS.
+template <int XT>
+__device__ __forceinline__ void conv_stats_epilogue(const ConvParams& p, f32x16 (&acc)[2][2][XT], float* smem, int rec, int co0, int oy0, int ox0,
+                                                    int wv, int lane, int tid) {
+    const int half = lane >> 5, l31 = lane & 31;
+    float sv[32], sq[32];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float a = 0.f, b = 0.f;
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int xt = 0; xt < XT; ++xt) {
+                    const bool ok = oy0 + wv * 2 + rt < p.oh && ox0 + l31 + xt * 32 < p.ow;
+                    const float v = ok ? acc[mt][rt][xt][r] : 0.f;
+                    a += v;
+                    b = fmaf(v, v, b);
+                }
+            sv[mt * 16 + r] = a;
+            sq[mt * 16 + r] = b;
+        }
+    const float ts = half_wave_reduce_scatter32(sv, l31), tq = half_wave_reduce_scatter32(sq, l31);
+    // lane (l31, half) now holds value index l31 = (mt, r) summed over the half-wave's 32 columns: channel mt*32 + mfma_row(r)
+    const int ch = (l31 >> 4) * 32 + (l31 & 3) + 8 * ((l31 & 15) >> 2) + 4 * half;
+    __syncthreads();                                   // every wave is done with the operand tiles: the LDS is free
+    smem[(0 * 4 + wv) * 64 + ch] = ts;
+    smem[(1 * 4 + wv) * 64 + ch] = tq;
+    __syncthreads();
+    if (tid < 128) {
+        const int st = tid >> 6, c = tid & 63;
+        const float t = (smem[(st * 4 + 0) * 64 + c] + smem[(st * 4 + 1) * 64 + c]) + (smem[(st * 4 + 2) * 64 + c] + smem[(st * 4 + 3) * 64 + c]);
+        if (co0 + c < p.cout) p.stats[((size_t)rec * 2 + st) * p.cout + co0 + c] = t;
+    }
+}
+
+template <int KH, int KW, int S, int CK, int XT, bool STATS = false>
 __global__ __launch_bounds__(256, (KH >= 9 ? 1 : 2)) void conv_fwd_kernel(const ConvParams p) {
     using C = ConvCfg<KH, KW, S, CK, XT>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -234,6 +276,7 @@ __global__ __launch_bounds__(256, (KH >= 9 ? 1 : 2)) void conv_fwd_kernel(const 
     }
 
     conv_epilogue<XT>(p, acc, n, co0, oy0, ox0, wv, lane);
+    if (STATS) conv_stats_epilogue<XT>(p, acc, smem, (n * p.tiles_y + ty) * p.tiles_x + tx, co0, oy0, ox0, wv, lane, tid);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -564,6 +607,13 @@ int launch_conv(ConvParams p, hipStream_t st) {
     p.co_blocks = ceil_div(p.cout, 64);
     const long grid = (long)p.tiles_x * p.tiles_y * p.co_blocks * p.n;
     if (grid <= 0 || grid > 0x7fffffffL) return VCG_E_SHAPE;
+    if (p.stats) {
+        // instantiated for the layers a normalisation follows in the fp32 configs: the trunk's 3x3 and the critics' 3x3 / 4x4 stride 1 and 2
+        if constexpr ((KH == 3 && KW == 3 && S <= 2) || (KH == 4 && KW == 4 && S <= 2))
+            return launch_with_lds(conv_fwd_kernel<KH, KW, S, CK, XT, true>, (int)grid, C::LDS_BYTES, p, st);
+        else
+            return VCG_E_UNSUPPORTED;
+    }
     return launch_with_lds(conv_fwd_kernel<KH, KW, S, CK, XT>, (int)grid, C::LDS_BYTES, p, st);
 }
 
@@ -599,9 +649,10 @@ int vcg_internal_conv9_rowchain(const float* x, const float* w, float* y, int n,
 // contiguous (or addressed by ws_* strides for the small-M kernel).
 int vcg_internal_conv(const float* x, const float* w, float* y, int n, int cin, int h, int wd, int cout,
                       int oh, int ow, int kh, int kw, int stride, int pad_top, int pad_left, int flip,
-                      const vcg_epilogue* ep, int smallm, int ws_t, int ws_m, int ws_k, hipStream_t st) {
+                      const vcg_epilogue* ep, int smallm, int ws_t, int ws_m, int ws_k, hipStream_t st, float* stats) {
     ConvParams p{};
-    p.x = x; p.w = w; p.y = y;
+    p.x = x; p.w = w; p.y = y; p.stats = stats;
+    if (stats && (smallm || cin <= 3)) return VCG_E_UNSUPPORTED;
     p.bias = ep ? ep->bias : nullptr;
     p.prelu = ep ? ep->prelu_alpha : nullptr;
     p.residual = ep ? ep->residual : nullptr;

@@ -202,7 +202,7 @@ __global__ void bn_fold_batch_kernel(FoldBatch fb, int c, float eps, float* scal
 __global__ __launch_bounds__(1024) void finalize_partials_kernel(const float* __restrict__ part, int nrec, int c, double inv_count,
                                                                   const float* gamma, const float* beta, float eps, float* mean_out,
                                                                   float* scale, float* shift, float* invstd, float* mmean, float* mvar,
-                                                                  float momentum, int unbiased_count, int groups) {
+                                                                  float momentum, int unbiased_count, int groups, const float* kshift) {
     __shared__ double rs[16][64], rq[16][64];
     const int cblocks = (c + 63) / 64, grp = blockIdx.x / cblocks, ch = (blockIdx.x - grp * cblocks) * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
     double s = 0.0, q = 0.0;
@@ -230,7 +230,9 @@ __global__ __launch_bounds__(1024) void finalize_partials_kernel(const float* __
     if (g != 0 || ch >= c) return;
 #pragma unroll
     for (int i = 1; i < 16; ++i) { s += rs[i][threadIdx.x]; q += rq[i][threadIdx.x]; }
-    const double m = s * inv_count, vd = q * inv_count - m * m;
+    // kshift: the records hold sums of (x - kshift[ch]) and of its square (the fp32 convolution's epilogue sums its accumulators, i.e. the
+    // output minus the bias): the variance is that of the shifted values, the mean gets the shift back
+    const double ms = s * inv_count, vd = q * inv_count - ms * ms, m = ms + (kshift ? (double)kshift[ch] : 0.0);
     const int i = grp * c + ch;
     const float mean = (float)m, var = vd > 0.0 ? (float)vd : 0.f;
     const float is = rsqrtf(var + eps);
@@ -496,7 +498,19 @@ int vcg_norm_finalize_partials(const float* part, int nrec, int groups, int c, d
     if (c <= 0 || groups <= 0 || nrec <= 0 || !(count > 0.0)) return VCG_E_SHAPE;
     if ((moving_mean == nullptr) != (moving_var == nullptr)) return VCG_E_NULL;
     hipLaunchKernelGGL(finalize_partials_kernel, dim3(groups * ceil_div(c, 64)), dim3(1024), 0, (hipStream_t)stream, part, nrec, c,
-                       1.0 / count, gamma, beta, eps, mean, scale, shift, invstd, moving_mean, moving_var, momentum, unbiased_count, groups);
+                       1.0 / count, gamma, beta, eps, mean, scale, shift, invstd, moving_mean, moving_var, momentum, unbiased_count, groups, nullptr);
+    VCG_LAUNCH_CHECK();
+    return VCG_OK;
+}
+
+int vcg_norm_finalize_partials_shifted(const float* part, int nrec, int groups, int c, double count, const float* kshift, const float* gamma,
+                                       const float* beta, float eps, float* mean, float* scale, float* shift, float* invstd, float* moving_mean,
+                                       float* moving_var, float momentum, int unbiased_count, vcg_stream_t stream) {
+    VCG_CHECK_PTR(part); VCG_CHECK_PTR(mean); VCG_CHECK_PTR(scale); VCG_CHECK_PTR(shift);
+    if (c <= 0 || groups <= 0 || nrec <= 0 || !(count > 0.0)) return VCG_E_SHAPE;
+    if ((moving_mean == nullptr) != (moving_var == nullptr)) return VCG_E_NULL;
+    hipLaunchKernelGGL(finalize_partials_kernel, dim3(groups * ceil_div(c, 64)), dim3(1024), 0, (hipStream_t)stream, part, nrec, c,
+                       1.0 / count, gamma, beta, eps, mean, scale, shift, invstd, moving_mean, moving_var, momentum, unbiased_count, groups, kshift);
     VCG_LAUNCH_CHECK();
     return VCG_OK;
 }

@@ -22,6 +22,7 @@ import os
 FUSED_STATS = os.environ.get("VCG_FUSED_STATS", "1") != "0"
 # VCG_FOLD_PREDICT=0: learning-phase-0 passes of the bf16 trunk as conv -> separate normalisation pass (A/B aid)
 FOLD_PREDICT = os.environ.get("VCG_FOLD_PREDICT", "1") != "0"
+STATS_EPILOGUE_F32 = os.environ.get("VCG_STATS_EPILOGUE_F32", "1") != "0"      # fp32 path: normalisation statistics from the convolutions' epilogues (A/B aid)
 
 BN_EPS = 1e-3          # keras BatchNormalization defaults
 BN_MOMENTUM = 0.99
@@ -259,6 +260,26 @@ class Conv2D(Layer):
                                           y.data_ptr(), ctypes.byref(ep), rt.stream), "vcg_conv2d_fwd[%s]" % self.name)
         return y, (x, y if self.act != L.ACT_NONE else None, d)
 
+    def forward_stats(self, x, instance, tag=None):
+        """forward (bias, no activation) whose epilogue leaves the statistics of the normalisation behind the layer: returns
+        (y, ctx, (records, records per group, shift)) for NormAct.forward(stats=...), or stats None where the layer's kernel has no
+        statistics epilogue (the normalisation then reads y itself)"""
+        rt = self.rt
+        n, _, h, w = x.shape
+        d = self.desc(n, h, w)
+        nrec = rt.lib.vcg_conv2d_stats_records(ctypes.byref(d), L.STATS_INSTANCE if instance else L.STATS_BATCH) if STATS_EPILOGUE_F32 else -1
+        if nrec <= 0 or self.act != L.ACT_NONE:
+            y, ctx = self.forward(x, tag=tag)
+            return y, ctx, None
+        y = rt.empty(n, self.cout, d.oh, d.ow)
+        total = nrec * (n if instance else 1)
+        rec = rt.empty(total * 2 * self.cout)
+        bias = self.ps[self.name + "/bias"]
+        with Timed(rt, tag):
+            L.check(rt.lib.vcg_conv2d_fwd_stats(ctypes.byref(d), x.data_ptr(), self.ps[self.name + "/kernel"].data_ptr(), bias.data_ptr(),
+                                                y.data_ptr(), rec.data_ptr(), rt.stream), "vcg_conv2d_fwd_stats[%s]" % self.name)
+        return y, (x, None, d), (rec, nrec, bias)
+
     def backward(self, ctx, dy, need_dx=True, param_grads=True, which=0, dx_residual=None, tag=None):
         rt = self.rt
         x, y, d = ctx
@@ -471,7 +492,13 @@ class NormAct(Layer):
     def _alpha_ptr(self):
         return self.ps[self.prelu_name + "/alpha"].data_ptr() if self.act == L.ACT_PRELU else None
 
-    def forward(self, x, training, residual=None, update_moving=True):
+    def needs_stats(self, training):
+        """does forward(x, training) compute statistics of x (so that a producer's epilogue may hand them over)"""
+        return self.norm is not None and bool(training or self.norm == "instance")
+
+    def forward(self, x, training, residual=None, update_moving=True, stats=None):
+        """stats: (records, records per group, shift) from the producing convolution's epilogue (Conv2D.forward_stats) -- one
+        vcg_norm_finalize_partials_shifted launch then replaces the statistics pass over x and vcg_norm_finalize"""
         rt, ps = self.rt, self.ps
         lib = rt.lib
         if x.dim() == 4:
@@ -492,7 +519,18 @@ class NormAct(Layer):
         scale, shift, invstd = rt.empty(rows * c), rt.empty(rows * c), rt.empty(rows * c)
         gamma = None if inst else ps[self.name + "/gamma"].data_ptr()
         beta = None if inst else ps[self.name + "/beta"].data_ptr()
-        if training or inst:
+        if (training or inst) and stats is not None:
+            buf, nrec, kshift = stats
+            mean = rt.empty(rows * c)
+            mm = mv = None
+            if not inst and update_moving:
+                mm, mv = ps[self.name + "/moving_mean"].data_ptr(), ps[self.name + "/moving_variance"].data_ptr()
+            L.check(lib.vcg_norm_finalize_partials_shifted(buf.data_ptr(), nrec, rows, c, float(hw if inst else n * hw), kshift.data_ptr(), gamma, beta,
+                                                           IN_EPS if inst else BN_EPS, mean.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+                                                           invstd.data_ptr(), mm, mv, BN_MOMENTUM, 0 if inst else n * hw, rt.stream),
+                    "vcg_norm_finalize_partials_shifted[%s]" % self.name)
+            saved = (mean, invstd)
+        elif training or inst:
             mean, var = rt.empty(rows * c), rt.empty(rows * c)
             ws, wsn = rt.workspace(lib.vcg_norm_stats_workspace_bytes(n, c, hw, mode))
             L.check(lib.vcg_norm_stats(x.data_ptr(), n, c, hw, mode, mean.data_ptr(), var.data_ptr(), ws, wsn, rt.stream),

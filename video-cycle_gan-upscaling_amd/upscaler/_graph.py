@@ -352,11 +352,22 @@ def build_model(inputs, outputs, name="model", seed=7):
                 if self._drop_step is None:
                     self._drop_step = torch.zeros(1, dtype=torch.int64, device=rt.device)
                 L.check(rt.lib.vcg_counter_inc(self._drop_step.data_ptr(), rt.stream), "vcg_counter_inc")
+            # conv node -> the norm node that reads it (one such consumer: its statistics come from the convolution's epilogue)
+            stat_consumer, pending = {}, {}
+            for j, (kj, lj, insj, _) in enumerate(g.nodes):
+                if kj == "norm" and g.nodes[insj[0]][0] == "conv":
+                    stat_consumer[insj[0]] = j if insj[0] not in stat_consumer else None
+            stat_consumer = {k: v for k, v in stat_consumer.items() if v is not None}
             for i, (kind, layer, ins, attrs) in enumerate(g.nodes):
                 if kind == "input":
                     continue
                 if kind in ("conv", "convt"):
-                    vals[i], tape[i] = layer.forward(vals[ins[0]])
+                    nj = stat_consumer.get(i)
+                    if nj is not None and g.nodes[nj][1].needs_stats(training):
+                        # the normalisation behind this convolution takes its statistics from the convolution's epilogue (as the hand-wired models do)
+                        vals[i], tape[i], pending[nj] = layer.forward_stats(vals[ins[0]], g.nodes[nj][1].norm == "instance")
+                    else:
+                        vals[i], tape[i] = layer.forward(vals[ins[0]])
                 elif kind == "gate":
                     a, m = vals[ins[0]], vals[ins[1]]
                     y = self.rt.empty(*m.shape)
@@ -411,7 +422,7 @@ def build_model(inputs, outputs, name="model", seed=7):
                     vals[i], tape[i] = y, None
                 else:
                     res = vals[ins[1]] if len(ins) > 1 else None
-                    vals[i], tape[i] = layer.forward(vals[ins[0]], training, residual=res)
+                    vals[i], tape[i] = layer.forward(vals[ins[0]], training, residual=res, stats=pending.pop(i, None))
             return vals[self.out_nid], tape
 
         def backward(self, tape, dy, which=0):

@@ -63,6 +63,9 @@ SIGNATURES = {
     "vcg_sum_records": (c_int, [_P, c_int, c_int, c_float, _P, _P]),
     "vcg_bn_fold": (c_int, [_P, _P, _P, _P, _P, c_int, c_float, _P, _P, _P]),
     "vcg_norm_finalize_partials": (c_int, [_P, c_int, c_int, c_int, ctypes.c_double, _P, _P, c_float, _P, _P, _P, _P, _P, _P, c_float, c_int, _P]),
+    "vcg_norm_finalize_partials_shifted": (c_int, [_P, c_int, c_int, c_int, ctypes.c_double, _P, _P, _P, c_float, _P, _P, _P, _P, _P, _P, c_float, c_int, _P]),
+    "vcg_conv2d_stats_records": (c_int, [_D, c_int]),
+    "vcg_conv2d_fwd_stats": (c_int, [_D, _P, _P, _P, _P, _P, _P]),
     "vcg_norm_act_fwd": (c_int, [_P, c_int, c_int, c_int, _P, _P, c_int, c_int, c_float, _P, _P, _P, _P]),
     "vcg_norm_act_bwd_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "vcg_norm_act_bwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_int, c_float, _P, c_int,

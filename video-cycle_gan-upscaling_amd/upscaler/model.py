@@ -486,7 +486,7 @@ class UpscalerOrig(Model):
             if bf and not training and nm.norm == "batch" and E.FOLD_PREDICT:
                 tape.extend((None, None))
                 return cv.forward_folded(h, nm, residual=residual, tag="trunk_conv", folded=folds.get(id(cv)))
-            if bf and nm.needs_stats(training):
+            if nm.needs_stats(training):          # (both dtypes: the convolution's epilogue hands the norm its statistics)
                 h, a, st = cv.forward_stats(h, nm.norm == "instance", tag="trunk_conv"); tape.append(a)
                 h, a = nm.forward(h, training, residual=residual, stats=st); tape.append(a)
             else:
@@ -630,7 +630,7 @@ class DiscriminatorStack(Model):
         for i, (cv, na) in enumerate(self.convs):
             if bf and i == 1 and not self.first_bf16:
                 h = E.to_bf16_nhwc(rt, h)
-            if bf and i > 0 and na.needs_stats(training):
+            if i > 0 and na.needs_stats(training) and cv.act == L.ACT_NONE:
                 h, a, st = cv.forward_stats(h, False, tag="d_conv"); tape.append(a)
                 h, a = na.forward(h, training, update_moving=update_moving, stats=st); tape.append(a)
                 continue
@@ -732,7 +732,7 @@ class DiscriminatorPatchGAN(Model):
                 h = E.to_bf16_nhwc(rt, h)
             if bf and i == last and not isinstance(cv, E.ConvCout1Bf16):
                 h = E.from_bf16_nhwc(rt, h)
-            if bf and na is not None and na.needs_stats(training):
+            if na is not None and na.needs_stats(training) and (bf or (0 < i < last and cv.act == L.ACT_NONE)):
                 h, a, st = cv.forward_stats(h, na.norm == "instance", tag="d_conv"); tape.append(a)
                 h, a = na.forward(h, training, update_moving=update_moving, stats=st); tape.append(a)
                 continue
